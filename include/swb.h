@@ -1,0 +1,208 @@
+/*
+ * swb.h -- C ABI of the MI355X-native batched Spriteworld step/render engine.
+ *
+ * The reference (google-deepmind/spriteworld) has no FFI / plugin registry: its
+ * hot path is one duck-typed Python call chain.  This
+ * header is therefore the boundary a maintainer would bind from Python
+ * (ctypes) to replace, for N environments at once:
+ *
+ *   spriteworld/environment.py:74-78    Environment.reset
+ *   spriteworld/environment.py:88-108   Environment.step
+ *   spriteworld/environment.py:80-86    Environment.success / should_terminate
+ *   spriteworld/action_spaces.py:65-104 SelectMove.step (+ DragAndDrop :133-137)
+ *   spriteworld/action_spaces.py:172-214 Embodied.step
+ *   spriteworld/tasks.py:70-81,126-158,196-245,248-296  NoReward /
+ *                                       FindGoalPosition / Clustering /
+ *                                       MetaAggregated reward + success
+ *   spriteworld/renderers/pil_renderer.py:67-91  PILRenderer.render
+ *   spriteworld/sprite.py:96-138        Sprite geometry, move, contains_point
+ *
+ * Conventions: every function returns 0 on success and a negative swb_status on
+ * error (message via swb_last_error()); no exceptions cross the boundary; plain
+ * pointers and sizes only.  "dev" pointers are HIP device pointers owned by the
+ * caller (e.g. torch tensors' data_ptr()); "host" pointers are ordinary host
+ * memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * One caller thread per handle; all launches are asynchronous w.r.t. `stream`.
+ *
+ * The same structs (swb_config, swb_task) are consumed by the CPU oracle
+ * (oracle/sw_oracle.c) so that tests feed both sides identical inputs.
+ */
+#ifndef SWB_H_
+#define SWB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWB_MAX_SPRITES 16   /* per environment                                 */
+#define SWB_MAX_TASKS 8      /* sub-tasks of a MetaAggregated task              */
+#define SWB_MAX_SHAPES 32
+#define SWB_MAX_SHAPE_VERTS 64 /* per shape (reference max is 30, the "circle") */
+
+enum swb_status {
+  SWB_OK = 0,
+  SWB_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+  SWB_ERR_HIP = -2,       /* HIP runtime error                        */
+  SWB_ERR_NO_DEVICE = -3, /* no usable gfx950 device                  */
+  SWB_ERR_STATE = -4      /* call order (e.g. step before set_pool)   */
+};
+
+/* action_spaces.py: which class the `actions` buffer is interpreted as. */
+enum swb_action_space {
+  SWB_ACTION_SELECT_MOVE = 0,   /* f64[N,4]  action_spaces.py:29-111  */
+  SWB_ACTION_DRAG_AND_DROP = 1, /* f64[N,4]  action_spaces.py:114-137 */
+  SWB_ACTION_EMBODIED = 2       /* i32[N,2]  action_spaces.py:140-221 */
+};
+
+enum swb_task_kind {
+  SWB_TASK_NO_REWARD = 0,  /* tasks.py:70-81   */
+  SWB_TASK_FIND_GOAL = 1,  /* tasks.py:84-158  */
+  SWB_TASK_CLUSTERING = 2  /* tasks.py:161-245 */
+};
+
+/* tasks.py:250-256 MetaAggregated.REWARD_AGGREGATOR / TERMINATION_CRITERION. */
+enum swb_meta_aggregator { SWB_AGG_SUM = 0, SWB_AGG_MAX = 1, SWB_AGG_MIN = 2, SWB_AGG_MEAN = 3 };
+enum swb_meta_termination { SWB_TERM_ALL = 0, SWB_TERM_ANY = 1 };
+
+/* dm_env.StepType values (environment.py:78,105-108). */
+enum swb_step_type { SWB_STEP_FIRST = 0, SWB_STEP_MID = 1, SWB_STEP_LAST = 2 };
+
+/* Per-environment error bits written to swb_outputs.error. */
+enum swb_env_error {
+  SWB_ENV_OK = 0,
+  SWB_ENV_ERR_DB_ZERO = 1,       /* Davies-Bouldin score 0 => reference raises ZeroDivisionError (tasks.py:215) */
+  SWB_ENV_ERR_DB_LABELS = 2,     /* sklearn check_number_of_labels => reference raises ValueError            */
+  SWB_ENV_ERR_SPAN_OVERFLOW = 4  /* internal raster span list overflow (never expected)                      */
+};
+
+/* One (sub-)task.  Field names follow the reference attributes they lower
+ * (tasks.py:118-124 FindGoalPosition, tasks.py:189-194 Clustering). */
+typedef struct swb_task {
+  int32_t kind;               /* swb_task_kind                                        */
+  int32_t sparse_reward;      /* _sparse_reward                                       */
+  double goal_position[2];    /* FindGoal: _goal_position                             */
+  double weights_dimensions[2];/* FindGoal: _weights_dimensions                       */
+  double terminate_distance;  /* FindGoal: _terminate_distance                        */
+  double raw_reward_multiplier;/* FindGoal: _raw_reward_multiplier                    */
+  double terminate_bonus;     /* both: _terminate_bonus                               */
+  double termination_threshold;/* Clustering: _termination_threshold                  */
+  double reward_range;        /* Clustering: _reward_range                            */
+} swb_task;
+
+typedef struct swb_config {
+  int32_t n_envs;             /* N                                                    */
+  int32_t max_sprites;        /* S <= SWB_MAX_SPRITES (per-episode count may be less) */
+  int32_t image_h;            /* PILRenderer image_size[0]                            */
+  int32_t image_w;            /* PILRenderer image_size[1]                            */
+  int32_t anti_aliasing;      /* PILRenderer anti_aliasing (1..5)                     */
+  uint8_t bg_rgb[4];          /* PILRenderer bg_color (4th byte unused)               */
+  int32_t action_space;       /* swb_action_space                                     */
+  double action_scale;        /* SelectMove/DragAndDrop _scale ; Embodied _step_size  */
+  double motion_cost;         /* _motion_cost                                         */
+  int32_t keep_in_frame;      /* Environment keep_in_frame                            */
+  int32_t max_episode_length; /* Environment max_episode_length                       */
+  int32_t pos_is_f32;         /* 1: sprite positions are np.float32 arrays (config-   */
+                              /* sampled sprites); 0: float64             */
+  int32_t n_tasks;            /* 1 for a plain task; >=1 with is_meta                 */
+  int32_t is_meta;            /* task is tasks.MetaAggregated                         */
+  int32_t meta_aggregator;    /* swb_meta_aggregator                                  */
+  int32_t meta_termination;   /* swb_meta_termination                                 */
+  double meta_terminate_bonus;/* MetaAggregated _terminate_bonus                      */
+  swb_task tasks[SWB_MAX_TASKS];
+} swb_config;
+
+/* A pool of initial states ("what init_sprites() returned"), host memory,
+ * entry-major: element e*S + s.  Entry e holds n_sprites[e] <= S sprites in
+ * back-to-front order (sprite_generators.py / environment.py:75).
+ * Everything static per episode is resolved on the host by the caller:
+ *   cos_a/sin_a = math.cos/sin(math.radians(angle))     (sprite.py:96-101)
+ *   rgb         = renderer _color_to_rgb(sprite.color)  (pil_renderer.py:82)
+ *   label[t]    = FindGoal: filter_distrib.contains(factors) (tasks.py:134-137)
+ *                 Clustering: first matching cluster index or -1 (tasks.py:196-205)
+ * Environment n draws entries pool_base[n] + (k mod pool_len[n]), k = 0,1,2...
+ */
+typedef struct swb_pool {
+  int32_t n_entries;          /* P                                                    */
+  const int32_t* n_sprites;   /* [P]                                                  */
+  const double* x;            /* [P,S]                                                */
+  const double* y;            /* [P,S]                                                */
+  const double* x_vel;        /* [P,S]                                                */
+  const double* y_vel;        /* [P,S]                                                */
+  const double* scale;        /* [P,S]                                                */
+  const double* cos_a;        /* [P,S]                                                */
+  const double* sin_a;        /* [P,S]                                                */
+  const int32_t* shape;       /* [P,S]  index into the uploaded shape table           */
+  const uint8_t* rgb;         /* [P,S,4] (r,g,b,unused)                               */
+  const int8_t* label;        /* [P,n_tasks,S]                                        */
+  const int32_t* pool_base;   /* [N]                                                  */
+  const int32_t* pool_len;    /* [N]                                                  */
+} swb_pool;
+
+/* Per-step outputs, device memory, caller-owned.  Any pointer may be NULL. */
+typedef struct swb_outputs {
+  uint8_t* obs;        /* u8 [N, H, W, 3]  PILRenderer.render (pil_renderer.py:67-91)      */
+  double* reward;      /* f64[N]  NaN on FIRST steps (dm_env reward=None)                  */
+  float* discount;     /* f32[N]  NaN on FIRST, 1 on MID, 0 on LAST                        */
+  uint8_t* step_type;  /* u8 [N]  swb_step_type                                            */
+  uint8_t* success;    /* u8 [N]  task.success(sprites) (renderers Success, handcrafted.py:115-131) */
+  uint8_t* error;      /* u8 [N]  swb_env_error bits                                       */
+} swb_outputs;
+
+/* Live state snapshot (host memory, caller-allocated) for parity tests and
+ * checkpointing (Environment.state(), environment.py:128-134). */
+typedef struct swb_state {
+  double* x;            /* [N,S] */
+  double* y;            /* [N,S] */
+  int32_t* n_sprites;   /* [N]   */
+  int32_t* pool_entry;  /* [N]   current episode's pool entry */
+  int32_t* step_count;  /* [N]   */
+  uint8_t* reset_next;  /* [N]   */
+  int32_t* episode;     /* [N]   number of resets so far */
+} swb_state;
+
+typedef struct swb_engine* swb_handle;
+
+const char* swb_last_error(void);
+int swb_version(void);
+
+/* Lifecycle. `device` is the HIP device ordinal. */
+int swb_create(const swb_config* cfg, int device, swb_handle* out);
+int swb_destroy(swb_handle h);
+
+/* constants.SHAPES (constants.py:27-40): vertices f64 [total,2], offsets[n_shapes+1]. */
+int swb_upload_shapes(swb_handle h, const double* verts, const int32_t* offsets, int32_t n_shapes);
+
+/* PIL ImagingResample 8bpc coefficient tables for one axis (host-computed, see
+ * spriteworld_amd/lanczos.py): bounds i32[out,2] (xmin,len), coeffs i32[out,ksize]. */
+int swb_upload_resample(swb_handle h, int32_t axis /*0=horizontal,1=vertical*/, int32_t out_size,
+                        int32_t ksize, const int32_t* bounds, const int32_t* coeffs);
+
+/* Install the reset pool and mark every environment "reset on next step"
+ * (Environment.__init__, environment.py:68-70). */
+int swb_set_pool(swb_handle h, const swb_pool* pool);
+
+/* Environment.reset() for all envs: the next swb_step is a FIRST step. */
+int swb_reset_all(swb_handle h, void* stream);
+
+/* Environment.step(): actions_dev is f64[N,4] (SelectMove/DragAndDrop) or
+ * i32[N,2] (Embodied). */
+int swb_step(swb_handle h, const void* actions_dev, const swb_outputs* out, void* stream);
+
+/* observation() only (no state change): obs_dev u8[N,H,W,3]. */
+int swb_render(swb_handle h, uint8_t* obs_dev, void* stream);
+
+/* Blocking state access (synchronises `stream`). */
+int swb_get_state(swb_handle h, const swb_state* host_state, void* stream);
+int swb_set_positions(swb_handle h, const double* x_host, const double* y_host, void* stream);
+
+/* Kernel timing: HIP events recorded on `stream` around every swb_step launch
+ * while enabled; swb_step_time_ms returns (total ms, launches) since enable. */
+int swb_timing_enable(swb_handle h, int32_t enable);
+int swb_step_time_ms(swb_handle h, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWB_H_ */

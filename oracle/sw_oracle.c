@@ -1,0 +1,890 @@
+/*
+ * sw_oracle.c -- CPU ORACLE for the batched Spriteworld step/render hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may build, load or call this file.  The product
+ * (spriteworld_amd/) never does; it fails loudly when its HIP library is missing.
+ *
+ * It is a plain scalar C restatement of the reference's algorithm for
+ * Environment.step() and everything under it.  Each function cites the reference
+ * file:line it follows.  Where the arithmetic lives in un-vendored, un-pinned
+ * third-party native code the published algorithm of the
+ * version installed in the build container is restated and named:
+ *   Pillow 12.2.0      libImaging Draw.c (polygon_generic, add_edge, hline) and
+ *                      Resample.c (precompute_coeffs, normalize_coeffs_8bpc,
+ *                      ImagingResampleHorizontal/Vertical_8bpc)
+ *   matplotlib 3.10.8  src/_path.h (affine_transform_2d, point_in_path with
+ *                      radius 0), lib/matplotlib/transforms.py (Affine2D)
+ *   scikit-learn 1.7.2 metrics/cluster/_unsupervised.py davies_bouldin_score,
+ *                      metrics/pairwise.py _euclidean_distances(_upcast)
+ *   numpy 2.2.6        pairwise summation (umath loops), NEP-50 promotion
+ *   glibc 2.35         pow() -- the reference computes `x ** 0.5` on a
+ *                      np.float64 scalar (tasks.py:127-128) which is libm pow,
+ *                      NOT sqrt (they differ in ~0.09 % of inputs); the oracle
+ *                      calls the same libm pow.
+ * Parity pinning: tests/test_oracle_vs_reference.py runs this oracle against the
+ * unmodified reference imported from /root/reference (frames, positions,
+ * rewards, step types) and against the golden vectors in tests/golden/ that
+ * were generated from the reference by tests/golden/make_golden.py, plus the
+ * reference's own known-answer tests re-expressed in tests/test_reference_kats.py.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no fast-math).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/swb.h"
+
+#define PRECISION_BITS (32 - 8 - 2) /* Pillow Resample.c */
+
+/* ------------------------------------------------------------------------- */
+/* Shape tables: constants.SHAPES (constants.py:27-40), uploaded verbatim.    */
+/* ------------------------------------------------------------------------- */
+static double g_verts[SWB_MAX_SHAPES * SWB_MAX_SHAPE_VERTS * 2];
+static int g_off[SWB_MAX_SHAPES + 1];
+static int g_nshapes = 0;
+
+int swo_set_shapes(const double* verts, const int32_t* offsets, int32_t n_shapes) {
+  if (n_shapes < 1 || n_shapes > SWB_MAX_SHAPES) return -1;
+  int total = offsets[n_shapes];
+  if (total > SWB_MAX_SHAPES * SWB_MAX_SHAPE_VERTS) return -1;
+  for (int i = 0; i <= n_shapes; ++i) g_off[i] = offsets[i];
+  memcpy(g_verts, verts, sizeof(double) * 2 * (size_t)total);
+  g_nshapes = n_shapes;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Sprite geometry.                                                           */
+/* ------------------------------------------------------------------------- */
+
+/* sprite.py:96-101 Sprite._reset_centered_path: Affine2D().scale(s) +
+ * Affine2D().rotate_deg(angle) => M = R*S = [[a*s, -b*s],[b*s, a*s]] with
+ * a = cos, b = sin (host-computed); then matplotlib _path.h affine_transform_2d:
+ * t0 = m00*x; t1 = m01*y; out = t0 + t1 + e, no FMA. */
+static int centered_path(int shape, double scale, double ca, double sa, double* cx, double* cy) {
+  const int o = g_off[shape], n = g_off[shape + 1] - o;
+  const double m00 = ca * scale, m01 = -sa * scale, m10 = sa * scale, m11 = ca * scale;
+  for (int i = 0; i < n; ++i) {
+    const double vx = g_verts[2 * (o + i)], vy = g_verts[2 * (o + i) + 1];
+    double t0 = m00 * vx, t1 = m01 * vy;
+    cx[i] = t0 + t1 + 0.0;
+    t0 = m10 * vx;
+    t1 = m11 * vy;
+    cy[i] = t0 + t1 + 0.0;
+  }
+  return n;
+}
+
+/* sprite.py:113-115 Sprite.contains_point -> matplotlib Path.contains_point ->
+ * _path.h point_in_path_impl, radius 0, closed polygon: even-odd crossing rule
+ * (SURVEY A.4).  (tx,ty) = point - position, in the sprite-centred frame. */
+static int point_in_centered_path(int n, const double* cx, const double* cy, double tx, double ty) {
+  int inside = 0;
+  double vx0 = cx[0], vy0 = cy[0];
+  int yflag0 = (vy0 >= ty);
+  for (int i = 1; i <= n; ++i) {
+    const double vx1 = cx[i % n], vy1 = cy[i % n];
+    const int yflag1 = (vy1 >= ty);
+    if (yflag0 != yflag1) {
+      if (((vy1 - ty) * (vx0 - vx1) >= (vx1 - tx) * (vy0 - vy1)) == yflag1) inside ^= 1;
+    }
+    yflag0 = yflag1;
+    vx0 = vx1;
+    vy0 = vy1;
+  }
+  return inside;
+}
+
+int swo_contains_point(int shape, double scale, double ca, double sa, double tx, double ty) {
+  double cx[SWB_MAX_SHAPE_VERTS], cy[SWB_MAX_SHAPE_VERTS];
+  const int n = centered_path(shape, scale, ca, sa, cx, cy);
+  return point_in_centered_path(n, cx, cy, tx, ty);
+}
+
+/* sprite.py:128-133 Sprite.vertices: Affine2D().translate(*position) applied to
+ * the centred path: (1*x + 0*y) + px. */
+int swo_vertices(int shape, double scale, double ca, double sa, double px, double py, double* out_xy) {
+  double cx[SWB_MAX_SHAPE_VERTS], cy[SWB_MAX_SHAPE_VERTS];
+  const int n = centered_path(shape, scale, ca, sa, cx, cy);
+  for (int i = 0; i < n; ++i) {
+    out_xy[2 * i] = 1.0 * cx[i] + 0.0 * cy[i] + px;
+    out_xy[2 * i + 1] = 0.0 * cx[i] + 1.0 * cy[i] + py;
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Pillow polygon fill (Draw.c).                                              */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int d;
+  int x0, y0;
+  int xmin, ymin, xmax, ymax;
+  float dx;
+} Edge;
+
+/* Draw.c add_edge */
+static void add_edge(Edge* e, int x0, int y0, int x1, int y1) {
+  if (x0 <= x1) { e->xmin = x0; e->xmax = x1; } else { e->xmin = x1; e->xmax = x0; }
+  if (y0 <= y1) { e->ymin = y0; e->ymax = y1; } else { e->ymin = y1; e->ymax = y0; }
+  if (y0 == y1) {
+    e->d = 0;
+    e->dx = 0.0f;
+  } else {
+    e->dx = ((float)(x1 - x0)) / (y1 - y0);
+    e->d = (y0 == e->ymin) ? 1 : -1;
+  }
+  e->x0 = x0;
+  e->y0 = y0;
+}
+
+/* Draw.c hline32 (RGB images are 4 bytes/pixel inside Pillow; here 3). */
+static void hline(uint8_t* im, int W, int H, int x0, int y0, int x1, const uint8_t* ink) {
+  if (y0 >= 0 && y0 < H) {
+    if (x0 < 0) x0 = 0; else if (x0 >= W) return;
+    if (x1 < 0) return; else if (x1 >= W) x1 = W - 1;
+    uint8_t* p = im + ((size_t)y0 * W) * 3;
+    for (; x0 <= x1; ++x0) { p[3 * x0] = ink[0]; p[3 * x0 + 1] = ink[1]; p[3 * x0 + 2] = ink[2]; }
+  }
+}
+
+static int x_cmp(const void* a, const void* b) {
+  const float fa = *(const float*)a, fb = *(const float*)b;
+  return (fa < fb) ? -1 : (fa > fb) ? 1 : 0;
+}
+
+/* Draw.c ROUND_UP / ROUND_DOWN */
+static int round_up(float f) {
+  return (int)((f >= 0.0f) ? floor(f + 0.5F) : -floor(fabs(f) + 0.5F));
+}
+static int round_down(float f) {
+  return (int)((f >= 0.0f) ? ceil(f - 0.5F) : -ceil(fabs(f) - 0.5F));
+}
+
+/* Draw.c polygon_generic, Pillow 12.2.0 (RGB / hline32 specialisation), restated
+ * from the installed binary's behaviour and pinned by differential tests against
+ * it (tests/test_oracle_vs_pil.py):
+ *  - horizontal edges are drawn immediately with hline and dropped;
+ *  - rows ymin..ymax with ymin clamped to 0 and ymax to im->ysize (not ysize-1);
+ *  - per row, in edge order, each active edge contributes its float32 crossing
+ *    x = (y - y0) * dx + x0;
+ *      * at the edge's lower end (y == edge.ymax) on any row but the last, the
+ *        crossing is duplicated ("needed to draw consistent polygons");
+ *      * otherwise, at an end point of the edge (y == edge.ymin, or y ==
+ *        edge.ymax on the last row) with dx != 0, the "connect discontiguous
+ *        corners" rule looks for an EARLIER edge k < i that also ends on this
+ *        row, has dx != 0, whose crossing rounds (roundf) to the same integer
+ *        and which is active on the adjacent row (next row; previous row when y
+ *        is this edge's ymax); with a, b the two edges' crossings on that
+ *        adjacent row the current crossing is replaced by roundf(fmax(a,b)) + 1
+ *        if it exceeds both a + 1 and b + 1, or by roundf(fmin(a,b)) - 1 if it
+ *        is below both a - 1 and b - 1; the search stops at the first such k;
+ *  - crossings are sorted and paired: hline(ROUND_UP(xx[i-1]), y, ROUND_DOWN(xx[i])). */
+static void polygon_generic(uint8_t* im, int W, int H, int n, Edge* e, const uint8_t* ink) {
+  if (n <= 0) return;
+  Edge* table[2 * SWB_MAX_SHAPE_VERTS];
+  float xx[4 * SWB_MAX_SHAPE_VERTS];
+  int edge_count = 0;
+  int ymin = H - 1, ymax = 0;
+  for (int i = 0; i < n; ++i) {
+    if (ymin > e[i].ymin) ymin = e[i].ymin;
+    if (ymax < e[i].ymax) ymax = e[i].ymax;
+    if (e[i].ymin == e[i].ymax) {
+      hline(im, W, H, e[i].xmin, e[i].ymin, e[i].xmax, ink);
+      continue;
+    }
+    table[edge_count++] = e + i;
+  }
+  if (ymin < 0) ymin = 0;
+  if (ymax > H) ymax = H;
+  for (; ymin <= ymax; ++ymin) {
+    int j = 0;
+    for (int i = 0; i < edge_count; ++i) {
+      Edge* cur = table[i];
+      if (ymin >= cur->ymin && ymin <= cur->ymax) {
+        xx[j++] = (ymin - cur->y0) * cur->dx + cur->x0;
+        if (ymin == cur->ymax && ymin < ymax) {
+          xx[j] = xx[j - 1];
+          j++;
+        } else if (cur->dx != 0 && (ymin == cur->ymin || ymin == cur->ymax)) {
+          const int adj_row = (ymin == cur->ymax) ? ymin - 1 : ymin + 1;
+          for (int k = 0; k < i; ++k) {
+            Edge* other = table[k];
+            if ((ymin != other->ymin && ymin != other->ymax) || other->dx == 0) continue;
+            if (roundf(xx[j - 1]) != roundf((ymin - other->y0) * other->dx + other->x0)) continue;
+            if (adj_row < other->ymin || adj_row > other->ymax) continue;
+            const float a = (adj_row - cur->y0) * cur->dx + cur->x0;
+            const float b = (adj_row - other->y0) * other->dx + other->x0;
+            if (xx[j - 1] > a + 1 && xx[j - 1] > b + 1)
+              xx[j - 1] = roundf((float)fmax(a, b)) + 1;
+            else if (xx[j - 1] < a - 1 && xx[j - 1] < b - 1)
+              xx[j - 1] = roundf((float)fmin(a, b)) - 1;
+            break;
+          }
+        }
+      }
+    }
+    qsort(xx, (size_t)j, sizeof(float), x_cmp);
+    for (int i = 1; i < j; i += 2)
+      hline(im, W, H, round_up(xx[i - 1]), ymin, round_down(xx[i]), ink);
+  }
+}
+
+/* Draw.c ImagingDrawPolygon (fill branch): edges between consecutive vertices,
+ * closing edge only if last != first. xy are the C-truncated coordinates. */
+static void draw_polygon(uint8_t* im, int W, int H, int count, const int* xy, const uint8_t* ink) {
+  Edge e[SWB_MAX_SHAPE_VERTS + 1];
+  int n = 0, i;
+  if (count <= 0) return;
+  for (i = 0; i < count - 1; ++i)
+    add_edge(&e[n++], xy[2 * i], xy[2 * i + 1], xy[2 * i + 2], xy[2 * i + 3]);
+  if (xy[2 * i] != xy[0] || xy[2 * i + 1] != xy[1])
+    add_edge(&e[n++], xy[2 * i], xy[2 * i + 1], xy[0], xy[1]);
+  polygon_generic(im, W, H, n, e, ink);
+}
+
+/* Raw entry for differential tests against PIL.ImageDraw.polygon. */
+int swo_fill_polygon(uint8_t* im, int W, int H, int count, const int32_t* xy, const uint8_t* ink) {
+  if (count > SWB_MAX_SHAPE_VERTS) return -1;
+  draw_polygon(im, W, H, count, (const int*)xy, ink);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Pillow LANCZOS resize, 8 bits per channel (Resample.c).                    */
+/* ------------------------------------------------------------------------- */
+static double sinc_filter(double x) {
+  if (x == 0.0) return 1.0;
+  x = x * M_PI;
+  return sin(x) / x;
+}
+static double lanczos_filter(double x) {
+  if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
+  return 0.0;
+}
+
+/* Resample.c precompute_coeffs + normalize_coeffs_8bpc for box (0, inSize).
+ * bounds: [out,2] = (xmin, count); kk: [out,ksize] int32. Returns ksize. */
+int swo_lanczos_ksize(int in_size, int out_size) {
+  double filterscale = (double)((float)in_size - 0.0f) / out_size;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 3.0 * filterscale;
+  return (int)ceil(support) * 2 + 1;
+}
+
+int swo_lanczos_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk) {
+  const float in0 = 0.0f, in1 = (float)in_size;
+  double filterscale, scale;
+  filterscale = scale = (double)(in1 - in0) / out_size;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 3.0 * filterscale;
+  const int ksize = (int)ceil(support) * 2 + 1;
+  double* k = (double*)malloc(sizeof(double) * (size_t)ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = in0 + (xx + 0.5) * scale;
+    double ww = 0.0;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    int x;
+    for (x = 0; x < xmax; ++x) {
+      const double w = lanczos_filter((x + xmin - center + 0.5) * ss);
+      k[x] = w;
+      ww += w;
+    }
+    for (x = 0; x < xmax; ++x)
+      if (ww != 0.0) k[x] /= ww;
+    for (; x < ksize; ++x) k[x] = 0;
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+    for (x = 0; x < ksize; ++x) {
+      if (k[x] < 0)
+        kk[xx * ksize + x] = (int)(-0.5 + k[x] * (1 << PRECISION_BITS));
+      else
+        kk[xx * ksize + x] = (int)(0.5 + k[x] * (1 << PRECISION_BITS));
+    }
+  }
+  free(k);
+  return ksize;
+}
+
+static uint8_t clip8(int in) {
+  const int v = in >> PRECISION_BITS; /* arithmetic shift, as Pillow's lookup index */
+  return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+/* Resample.c ImagingResample: horizontal pass then vertical pass, uint8
+ * intermediate, 3 bands.  src [Hc][Wc][3] -> dst [H][W][3]. */
+static void resample_lanczos(const uint8_t* src, int Wc, int Hc, uint8_t* dst, int W, int H) {
+  const int ksh = swo_lanczos_ksize(Wc, W), ksv = swo_lanczos_ksize(Hc, H);
+  int32_t* bh = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)W);
+  int32_t* kh = (int32_t*)malloc(sizeof(int32_t) * (size_t)W * ksh);
+  int32_t* bv = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)H);
+  int32_t* kv = (int32_t*)malloc(sizeof(int32_t) * (size_t)H * ksv);
+  swo_lanczos_coeffs(Wc, W, bh, kh);
+  swo_lanczos_coeffs(Hc, H, bv, kv);
+  uint8_t* tmp = (uint8_t*)malloc((size_t)Hc * W * 3);
+  for (int yy = 0; yy < Hc; ++yy)
+    for (int xx = 0; xx < W; ++xx) {
+      const int xmin = bh[2 * xx], xmax = bh[2 * xx + 1];
+      const int32_t* k = kh + xx * ksh;
+      int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+      for (int x = 0; x < xmax; ++x) {
+        const uint8_t* p = src + ((size_t)yy * Wc + (x + xmin)) * 3;
+        s0 += p[0] * k[x]; s1 += p[1] * k[x]; s2 += p[2] * k[x];
+      }
+      uint8_t* o = tmp + ((size_t)yy * W + xx) * 3;
+      o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+    }
+  for (int yy = 0; yy < H; ++yy) {
+    const int ymin = bv[2 * yy], ymax = bv[2 * yy + 1];
+    const int32_t* k = kv + yy * ksv;
+    for (int xx = 0; xx < W; ++xx) {
+      int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+      for (int y = 0; y < ymax; ++y) {
+        const uint8_t* p = tmp + ((size_t)(y + ymin) * W + xx) * 3;
+        s0 += p[0] * k[y]; s1 += p[1] * k[y]; s2 += p[2] * k[y];
+      }
+      uint8_t* o = dst + ((size_t)yy * W + xx) * 3;
+      o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+    }
+  }
+  free(tmp); free(bh); free(kh); free(bv); free(kv);
+}
+
+/* Raw entry for differential tests against PIL.Image.resize(LANCZOS). */
+int swo_resample(const uint8_t* src, int Wc, int Hc, uint8_t* dst, int W, int H) {
+  resample_lanczos(src, Wc, Hc, dst, W, H);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* PILRenderer.render (pil_renderer.py:67-91).                                */
+/* ------------------------------------------------------------------------- */
+/* The reference multiplies vertices (x, y) by canvas_size = (AA*image_size[0],
+ * AA*image_size[1]) and makes a PIL image of that *size* (PIL sizes are
+ * (width, height)), i.e. canvas width = AA*image_size[0]; np.array(image) is
+ * then (image_size[1], image_size[0], 3).  cfg->image_h = image_size[0],
+ * cfg->image_w = image_size[1]; for the (square) shipped configs the
+ * distinction vanishes.  We follow the reference's actual behaviour:
+ * PIL width Wp = AA*image_h, PIL height Hp = AA*image_w. */
+static void render_env(const swb_config* cfg, int n, const double* x, const double* y,
+                       const int32_t* shape, const double* scale, const double* ca,
+                       const double* sa, const uint8_t* rgb, uint8_t* obs) {
+  const int AA = cfg->anti_aliasing;
+  const int Wo = cfg->image_h, Ho = cfg->image_w;     /* PIL (width, height) of the output */
+  const int Wc = AA * Wo, Hc = AA * Ho;
+  uint8_t* canvas = (uint8_t*)malloc((size_t)Wc * Hc * 3);
+  for (size_t i = 0; i < (size_t)Wc * Hc; ++i) {      /* canvas.paste(bg) :79 */
+    canvas[3 * i] = cfg->bg_rgb[0]; canvas[3 * i + 1] = cfg->bg_rgb[1]; canvas[3 * i + 2] = cfg->bg_rgb[2];
+  }
+  double cx[SWB_MAX_SHAPE_VERTS], cy[SWB_MAX_SHAPE_VERTS];
+  int ixy[2 * SWB_MAX_SHAPE_VERTS];
+  for (int s = 0; s < n; ++s) {                         /* back to front :80-83 */
+    const int nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+    for (int i = 0; i < nv; ++i) {
+      const double vx = 1.0 * cx[i] + 0.0 * cy[i] + x[s]; /* sprite.py:131-133 */
+      const double vy = 0.0 * cx[i] + 1.0 * cy[i] + y[s];
+      ixy[2 * i] = (int)((double)Wc * vx);              /* canvas_size * vertices; C truncation in _imaging */
+      ixy[2 * i + 1] = (int)((double)Hc * vy);
+    }
+    draw_polygon(canvas, Wc, Hc, nv, ixy, rgb + 4 * s);
+  }
+  uint8_t* img = canvas;
+  uint8_t* small = NULL;
+  if (AA != 1) {                                        /* resize(..., ANTIALIAS) :84; same size => copy */
+    small = (uint8_t*)malloc((size_t)Wo * Ho * 3);
+    resample_lanczos(canvas, Wc, Hc, small, Wo, Ho);
+    img = small;
+  }
+  for (int r = 0; r < Ho; ++r)                          /* np.flipud :90 */
+    memcpy(obs + (size_t)r * Wo * 3, img + (size_t)(Ho - 1 - r) * Wo * 3, (size_t)Wo * 3);
+  free(canvas);
+  free(small);
+}
+
+/* ------------------------------------------------------------------------- */
+/* numpy reductions.                                                          */
+/* ------------------------------------------------------------------------- */
+/* numpy umath pairwise sum (loops_utils.h.src @TYPE@_pairwise_sum), float64. */
+static double np_pairwise_sum(const double* a, int n) {
+  if (n < 8) {
+    double res = -0.0;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  } else if (n <= 128) {
+    double r[8];
+    int i;
+    for (i = 0; i < 8; ++i) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  } else {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+  }
+}
+static float np_pairwise_sumf(const float* a, int n) {
+  if (n < 8) {
+    float res = -0.0f;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  } else if (n <= 128) {
+    float r[8];
+    int i;
+    for (i = 0; i < 8; ++i) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  } else {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sumf(a, n2) + np_pairwise_sumf(a + n2, n - n2);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Tasks.                                                                     */
+/* ------------------------------------------------------------------------- */
+/* tasks.py:126-158 FindGoalPosition.  label[s] != 0 <=> sprite passes the filter. */
+static void task_find_goal(const swb_task* t, int n, const double* x, const double* y,
+                           const int8_t* label, double* reward, int* success) {
+  double rewards[SWB_MAX_SPRITES];
+  int m = 0, all_ge0 = 1;
+  for (int s = 0; s < n; ++s) {
+    if (!label[s]) continue;
+    const double d0 = x[s] - t->goal_position[0], d1 = y[s] - t->goal_position[1];
+    const double w0 = t->weights_dimensions[0] * (d0 * d0), w1 = t->weights_dimensions[1] * (d1 * d1);
+    const double sum = w0 + w1;                       /* np.sum of 2 elements */
+    const double goal_distance = pow(sum, 0.5);       /* np.float64 ** 0.5 -> libm pow */
+    const double raw = t->terminate_distance - goal_distance;
+    rewards[m] = t->raw_reward_multiplier * raw;
+    if (!(rewards[m] >= 0)) all_ge0 = 0;
+    ++m;
+  }
+  *success = all_ge0;                                 /* all([]) is True */
+  if (m == 0) { *reward = NAN; return; }              /* tasks.py:145-146 */
+  const double dense = np_pairwise_sum(rewards, m);
+  double r = 0.0;
+  if (all_ge0) { r += t->terminate_bonus; r += dense; }
+  else if (!t->sparse_reward) { r += dense; }
+  *reward = r;
+}
+
+/* scikit-learn 1.7.2 davies_bouldin_score on the assigned sprites, following
+ * the float32 (`pos_f32`) or float64 position dtype path.
+ * Returns 0 ok, SWB_ENV_ERR_DB_LABELS or SWB_ENV_ERR_DB_ZERO. */
+static int g_fma_dot = 0; /* build-time pinned against sklearn; see swo_set_fma_dot */
+void swo_set_fma_dot(int v) { g_fma_dot = v; }
+
+static double dot2(double a0, double a1, double b0, double b1) {
+  if (g_fma_dot) return fma(a1, b1, a0 * b0);
+  return a0 * b0 + a1 * b1;
+}
+
+static int davies_bouldin(int pos_f32, int n, const double* x, const double* y, const int8_t* label,
+                          double* score_out) {
+  /* positions[cluster_assignments >= 0]; LabelEncoder -> sorted unique labels */
+  double px[SWB_MAX_SPRITES], py[SWB_MAX_SPRITES];
+  int lab[SWB_MAX_SPRITES], m = 0;
+  int present[128];
+  memset(present, 0, sizeof(present));
+  for (int s = 0; s < n; ++s)
+    if (label[s] >= 0) { px[m] = x[s]; py[m] = y[s]; lab[m] = label[s]; present[(int)label[s]] = 1; ++m; }
+  int remap[128], k = 0;
+  for (int c = 0; c < 128; ++c) remap[c] = present[c] ? k++ : -1;
+  if (!(1 < k && k < m)) return SWB_ENV_ERR_DB_LABELS; /* check_number_of_labels */
+  double intra[SWB_MAX_SPRITES], c0[SWB_MAX_SPRITES], c1[SWB_MAX_SPRITES];
+  for (int c = 0; c < k; ++c) {
+    int cnt = 0;
+    if (pos_f32) {
+      /* cluster_k.mean(axis=0) in float32: sequential row adds, then /n in f32 */
+      float s0 = 0.f, s1 = 0.f;
+      int first = 1;
+      for (int i = 0; i < m; ++i)
+        if (remap[lab[i]] == c) {
+          if (first) { s0 = (float)px[i]; s1 = (float)py[i]; first = 0; }
+          else { s0 += (float)px[i]; s1 += (float)py[i]; }
+          ++cnt;
+        }
+      const float m0 = s0 / (float)cnt, m1 = s1 / (float)cnt;
+      c0[c] = m0; c1[c] = m1;
+      /* pairwise_distances(cluster_k, [centroid]) -> _euclidean_distances_upcast:
+       * d = -2*X.Y^T + XX + YY in f64, cast to f32, max(.,0), sqrt in f32 */
+      float dist[SWB_MAX_SPRITES];
+      int j = 0;
+      const double yy = dot2(m0, m1, m0, m1);
+      for (int i = 0; i < m; ++i)
+        if (remap[lab[i]] == c) {
+          const double xxn = dot2(px[i], py[i], px[i], py[i]);
+          double d = -2 * dot2(px[i], py[i], m0, m1);
+          d += xxn;
+          d += yy;
+          float df = (float)d;
+          if (!(df > 0.0f)) df = 0.0f;     /* np.maximum(distances, 0) */
+          dist[j++] = sqrtf(df);
+        }
+      /* np.average -> mean of float32: pairwise sum in f32, / n in f32 */
+      const float avg = np_pairwise_sumf(dist, cnt) / (float)cnt;
+      intra[c] = avg;
+    } else {
+      double s0 = 0., s1 = 0.;
+      int first = 1;
+      for (int i = 0; i < m; ++i)
+        if (remap[lab[i]] == c) {
+          if (first) { s0 = px[i]; s1 = py[i]; first = 0; }
+          else { s0 += px[i]; s1 += py[i]; }
+          ++cnt;
+        }
+      const double m0 = s0 / (double)cnt, m1 = s1 / (double)cnt;
+      c0[c] = m0; c1[c] = m1;
+      double dist[SWB_MAX_SPRITES];
+      int j = 0;
+      const double yy = dot2(m0, m1, m0, m1);
+      for (int i = 0; i < m; ++i)
+        if (remap[lab[i]] == c) {
+          const double xxn = dot2(px[i], py[i], px[i], py[i]);
+          double d = -2 * dot2(px[i], py[i], m0, m1);
+          d += xxn;
+          d += yy;
+          if (!(d > 0.0)) d = 0.0;
+          dist[j++] = sqrt(d);
+        }
+      intra[c] = np_pairwise_sum(dist, cnt) / (double)cnt;
+    }
+  }
+  /* centroid_distances = pairwise_distances(centroids) (float64, X is Y) */
+  double D[SWB_MAX_SPRITES][SWB_MAX_SPRITES];
+  double nn[SWB_MAX_SPRITES];
+  for (int a = 0; a < k; ++a) nn[a] = dot2(c0[a], c1[a], c0[a], c1[a]);
+  int all_d_zero = 1, all_i_zero = 1;
+  for (int a = 0; a < k; ++a)
+    for (int b = 0; b < k; ++b) {
+      double d = -2 * dot2(c0[a], c1[a], c0[b], c1[b]);
+      d += nn[a];
+      d += nn[b];
+      if (!(d > 0.0)) d = 0.0;
+      if (a == b) d = 0.0;
+      D[a][b] = sqrt(d);
+      if (!(fabs(D[a][b]) <= 1e-8)) all_d_zero = 0;   /* np.allclose(., 0) */
+    }
+  for (int a = 0; a < k; ++a)
+    if (!(fabs(intra[a]) <= 1e-8)) all_i_zero = 0;
+  if (all_i_zero || all_d_zero) { *score_out = 0.0; return SWB_ENV_ERR_DB_ZERO; }
+  double scores[SWB_MAX_SPRITES];
+  for (int a = 0; a < k; ++a) {
+    double best = -INFINITY;
+    for (int b = 0; b < k; ++b) {
+      const double den = (D[a][b] == 0) ? INFINITY : D[a][b];
+      const double v = (intra[a] + intra[b]) / den;
+      if (b == 0 || v > best || isnan(v)) best = (isnan(best) ? best : v);
+    }
+    scores[a] = best;
+  }
+  *score_out = np_pairwise_sum(scores, k) / (double)k;
+  return 0;
+}
+
+int swo_davies_bouldin(int pos_f32, int n, const double* x, const double* y, const int8_t* label,
+                       double* score_out) {
+  return davies_bouldin(pos_f32, n, x, y, label, score_out);
+}
+
+/* tasks.py:196-245 Clustering. */
+static int task_clustering(const swb_task* t, int pos_f32, int n, const double* x, const double* y,
+                           const int8_t* label, double* reward, int* success) {
+  double score = 0.0;
+  const int err = davies_bouldin(pos_f32, n, x, y, label, &score);
+  if (err) { *reward = NAN; *success = 0; return err; }
+  const double metric = 1. / score;
+  const double dense = (metric - t->termination_threshold) * t->reward_range / 2.;
+  double r = 0.0;
+  const int ok = metric >= t->termination_threshold;
+  if (ok) { r += t->terminate_bonus; r += dense; }
+  else if (!t->sparse_reward) { r += dense; }
+  *reward = r;
+  *success = ok;
+  return 0;
+}
+
+static int eval_one_task(const swb_config* cfg, int ti, int n, const double* x, const double* y,
+                         const int8_t* label, double* reward, int* success) {
+  const swb_task* t = &cfg->tasks[ti];
+  switch (t->kind) {
+    case SWB_TASK_FIND_GOAL: task_find_goal(t, n, x, y, label, reward, success); return 0;
+    case SWB_TASK_CLUSTERING: return task_clustering(t, cfg->pos_is_f32, n, x, y, label, reward, success);
+    default: *reward = 0.0; *success = 0; return 0; /* NoReward tasks.py:70-81 */
+  }
+}
+
+/* task.reward + task.success incl. tasks.py:248-296 MetaAggregated.
+ * label: [n_tasks][S]. */
+static int eval_task(const swb_config* cfg, int n, const double* x, const double* y,
+                     const int8_t* label, double* reward, int* success) {
+  const int S = cfg->max_sprites;
+  if (!cfg->is_meta) return eval_one_task(cfg, 0, n, x, y, label, reward, success);
+  double r[SWB_MAX_TASKS];
+  int ok[SWB_MAX_TASKS], err = 0;
+  for (int t = 0; t < cfg->n_tasks; ++t) err |= eval_one_task(cfg, t, n, x, y, label + t * S, &r[t], &ok[t]);
+  int succ = (cfg->meta_termination == SWB_TERM_ALL);
+  for (int t = 0; t < cfg->n_tasks; ++t)
+    succ = (cfg->meta_termination == SWB_TERM_ALL) ? (succ && ok[t]) : (succ || ok[t]);
+  double agg;
+  double vals[SWB_MAX_TASKS];
+  int cnt = 0;
+  switch (cfg->meta_aggregator) {
+    case SWB_AGG_SUM: /* np.nansum: NaN -> 0 then np.sum */
+      for (int t = 0; t < cfg->n_tasks; ++t) vals[t] = isnan(r[t]) ? 0.0 : r[t];
+      agg = np_pairwise_sum(vals, cfg->n_tasks);
+      break;
+    case SWB_AGG_MEAN: /* np.nanmean: nansum / count of non-NaN */
+      for (int t = 0; t < cfg->n_tasks; ++t) { vals[t] = isnan(r[t]) ? 0.0 : r[t]; cnt += !isnan(r[t]); }
+      agg = np_pairwise_sum(vals, cfg->n_tasks) / (double)cnt;
+      break;
+    case SWB_AGG_MAX:
+      agg = NAN;
+      for (int t = 0; t < cfg->n_tasks; ++t) if (!isnan(r[t]) && (isnan(agg) || r[t] > agg)) agg = r[t];
+      break;
+    default:
+      agg = NAN;
+      for (int t = 0; t < cfg->n_tasks; ++t) if (!isnan(r[t]) && (isnan(agg) || r[t] < agg)) agg = r[t];
+      break;
+  }
+  agg += cfg->meta_terminate_bonus * (double)succ; /* tasks.py:291 */
+  *reward = agg;
+  *success = succ;
+  return err;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Environment state machine.                                                 */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  swb_config cfg;
+  /* pool (copied) */
+  int P;
+  int32_t *p_n, *p_shape, *pool_base, *pool_len;
+  double *p_x, *p_y, *p_xv, *p_yv, *p_scale, *p_ca, *p_sa;
+  uint8_t* p_rgb;
+  int8_t* p_label;
+  /* live */
+  double *x, *y;
+  int32_t *n, *entry, *step_count, *episode;
+  uint8_t* reset_next;
+} swo_engine;
+
+static void* dup_mem(const void* p, size_t bytes) {
+  void* q = malloc(bytes ? bytes : 1);
+  memcpy(q, p, bytes);
+  return q;
+}
+
+swo_engine* swo_create(const swb_config* cfg, const swb_pool* pool) {
+  swo_engine* e = (swo_engine*)calloc(1, sizeof(swo_engine));
+  e->cfg = *cfg;
+  const int N = cfg->n_envs, S = cfg->max_sprites, P = pool->n_entries, T = cfg->n_tasks;
+  e->P = P;
+  e->p_n = dup_mem(pool->n_sprites, sizeof(int32_t) * P);
+  e->p_shape = dup_mem(pool->shape, sizeof(int32_t) * P * S);
+  e->pool_base = dup_mem(pool->pool_base, sizeof(int32_t) * N);
+  e->pool_len = dup_mem(pool->pool_len, sizeof(int32_t) * N);
+  e->p_x = dup_mem(pool->x, sizeof(double) * P * S);
+  e->p_y = dup_mem(pool->y, sizeof(double) * P * S);
+  e->p_xv = dup_mem(pool->x_vel, sizeof(double) * P * S);
+  e->p_yv = dup_mem(pool->y_vel, sizeof(double) * P * S);
+  e->p_scale = dup_mem(pool->scale, sizeof(double) * P * S);
+  e->p_ca = dup_mem(pool->cos_a, sizeof(double) * P * S);
+  e->p_sa = dup_mem(pool->sin_a, sizeof(double) * P * S);
+  e->p_rgb = dup_mem(pool->rgb, (size_t)P * S * 4);
+  e->p_label = dup_mem(pool->label, (size_t)P * T * S);
+  e->x = calloc((size_t)N * S, sizeof(double));
+  e->y = calloc((size_t)N * S, sizeof(double));
+  e->n = calloc(N, sizeof(int32_t));
+  e->entry = calloc(N, sizeof(int32_t));
+  e->step_count = calloc(N, sizeof(int32_t));
+  e->episode = calloc(N, sizeof(int32_t));
+  e->reset_next = malloc(N);
+  memset(e->reset_next, 1, N);                       /* environment.py:70 */
+  /* environment.py:68 the constructor already calls init_sprites() once; the
+   * caller accounts for that draw when it builds the pool (entry k is the k-th
+   * reset). */
+  return e;
+}
+
+void swo_destroy(swo_engine* e) {
+  if (!e) return;
+  free(e->p_n); free(e->p_shape); free(e->pool_base); free(e->pool_len);
+  free(e->p_x); free(e->p_y); free(e->p_xv); free(e->p_yv); free(e->p_scale);
+  free(e->p_ca); free(e->p_sa); free(e->p_rgb); free(e->p_label);
+  free(e->x); free(e->y); free(e->n); free(e->entry); free(e->step_count);
+  free(e->episode); free(e->reset_next); free(e);
+}
+
+void swo_reset_all(swo_engine* e) { memset(e->reset_next, 1, e->cfg.n_envs); }
+
+/* sprite.py:103-107 Sprite.move with numpy in-place semantics: float32
+ * positions round after the float64 add. */
+static double move1(int pos_f32, double p, double motion, int keep) {
+  double q = p + motion;
+  if (pos_f32) q = (double)(float)q;
+  if (keep) { if (q < 0.0) q = 0.0; if (q > 1.0) q = 1.0; }  /* np.clip(pos, 0., 1.) */
+  return q;
+}
+
+static void observe(swo_engine* e, int i, uint8_t* obs, uint8_t* succ_out, uint8_t* err_out,
+                    double* task_reward) {
+  const swb_config* c = &e->cfg;
+  const int S = c->max_sprites, en = e->entry[i], n = e->n[i];
+  double r = 0; int ok = 0;
+  const int err = eval_task(c, n, e->x + i * S, e->y + i * S, e->p_label + (size_t)en * c->n_tasks * S, &r, &ok);
+  if (task_reward) *task_reward = r;
+  if (succ_out) *succ_out = (uint8_t)ok;
+  if (err_out) *err_out = (uint8_t)err;
+  if (obs)
+    render_env(c, n, e->x + i * S, e->y + i * S, e->p_shape + en * S, e->p_scale + en * S,
+               e->p_ca + en * S, e->p_sa + en * S, e->p_rgb + (size_t)en * S * 4,
+               obs + (size_t)i * c->image_h * c->image_w * 3);
+}
+
+/* environment.py:88-108 Environment.step for env range [i0, i1).
+ * actions: f64[N,4] or i32[N,2].  Output arrays may be NULL. */
+int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* obs, double* reward,
+                   float* discount, uint8_t* step_type, uint8_t* success, uint8_t* error) {
+  const swb_config* c = &e->cfg;
+  const int S = c->max_sprites;
+  for (int i = i0; i < i1; ++i) {
+    double* x = e->x + i * S;
+    double* y = e->y + i * S;
+    if (e->reset_next[i]) {                              /* :90-91 -> reset() :74-78 */
+      const int en = e->pool_base[i] + (e->episode[i] % e->pool_len[i]);
+      e->entry[i] = en;
+      e->episode[i] += 1;
+      e->n[i] = e->p_n[en];
+      for (int s = 0; s < S; ++s) { x[s] = e->p_x[en * S + s]; y[s] = e->p_y[en * S + s]; }
+      e->step_count[i] = 0;
+      e->reset_next[i] = 0;
+      observe(e, i, obs, success ? success + i : NULL, error ? error + i : NULL, NULL);
+      if (reward) reward[i] = NAN;                       /* dm_env.restart: reward None */
+      if (discount) discount[i] = NAN;
+      if (step_type) step_type[i] = SWB_STEP_FIRST;
+      continue;
+    }
+    const int en = e->entry[i], n = e->n[i];
+    const int32_t* shape = e->p_shape + en * S;
+    const double *scale = e->p_scale + en * S, *ca = e->p_ca + en * S, *sa = e->p_sa + en * S;
+    e->step_count[i] += 1;                               /* :93 */
+    double cost = 0.0;
+    double cx[SWB_MAX_SHAPE_VERTS], cy[SWB_MAX_SHAPE_VERTS];
+    if (c->action_space == SWB_ACTION_EMBODIED) {        /* action_spaces.py:187-214 */
+      const int32_t* a = (const int32_t*)actions + 2 * i;
+      const double st = c->action_scale;
+      double m0 = 0, m1 = 0;                             /* action_to_motion :165-170 */
+      switch (a[1]) { case 0: m1 = st; break; case 1: m0 = -st; break; case 2: m1 = -st; break; default: m0 = st; }
+      if (n > 0) {
+        const int body = n - 1;
+        if (a[0]) {                                      /* get_carried_sprite :180-185 */
+          for (int s = body - 1; s >= 0; --s) {
+            double tx, ty;
+            if (c->pos_is_f32) {                         /* f32 - f32 -> f32 */
+              tx = (double)((float)x[body] - (float)x[s]);
+              ty = (double)((float)y[body] - (float)y[s]);
+            } else { tx = x[body] - x[s]; ty = y[body] - y[s]; }
+            const int nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+            if (point_in_centered_path(nv, cx, cy, tx, ty)) {
+              x[s] = move1(c->pos_is_f32, x[s], m0, c->keep_in_frame);
+              y[s] = move1(c->pos_is_f32, y[s], m1, c->keep_in_frame);
+              break;
+            }
+          }
+        }
+        x[body] = move1(c->pos_is_f32, x[body], m0, c->keep_in_frame);
+        y[body] = move1(c->pos_is_f32, y[body], m1, c->keep_in_frame);
+      }
+      cost = -c->motion_cost * st;                       /* :214 */
+    } else {                                             /* action_spaces.py:83-104 */
+      const double* a = (const double*)actions + 4 * i;
+      double m0, m1;
+      if (c->action_space == SWB_ACTION_DRAG_AND_DROP) { /* :133-137 */
+        m0 = (a[2] - a[0]) * c->action_scale; m1 = (a[3] - a[1]) * c->action_scale;
+      } else {                                           /* :65-67 */
+        m0 = (a[2] - 0.5) * c->action_scale; m1 = (a[3] - 0.5) * c->action_scale;
+      }
+      for (int s = n - 1; s >= 0; --s) {                 /* sprites[::-1] :77-81 */
+        const double tx = a[0] - x[s], ty = a[1] - y[s]; /* f64 - f32 -> f64 */
+        const int nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+        if (point_in_centered_path(nv, cx, cy, tx, ty)) {
+          x[s] = move1(c->pos_is_f32, x[s], m0, c->keep_in_frame);
+          y[s] = move1(c->pos_is_f32, y[s], m1, c->keep_in_frame);
+          break;
+        }
+      }
+      /* np.linalg.norm(motion) = sqrt(dot(m, m)) :104 */
+      cost = -c->motion_cost * sqrt(dot2(m0, m1, m0, m1));
+    }
+    for (int s = 0; s < n; ++s) {                        /* update_position :98-99 */
+      x[s] = move1(c->pos_is_f32, x[s], e->p_xv[en * S + s], c->keep_in_frame);
+      y[s] = move1(c->pos_is_f32, y[s], e->p_yv[en * S + s], c->keep_in_frame);
+    }
+    double tr = 0; uint8_t ok = 0, err = 0;
+    observe(e, i, obs, &ok, &err, &tr);                  /* :101-102 */
+    if (success) success[i] = ok;
+    if (error) error[i] = err;
+    if (reward) reward[i] = cost + tr;                   /* reward += task.reward */
+    int oof = 0;                                         /* sprite.py:135-138 */
+    for (int s = 0; s < n; ++s)
+      if (!(x[s] >= 0. && y[s] >= 0. && x[s] <= 1. && y[s] <= 1.)) oof = 1;
+    const int timeout = e->step_count[i] >= c->max_episode_length; /* :84 */
+    if (ok || oof || timeout) {                          /* :104-106 */
+      e->reset_next[i] = 1;
+      if (step_type) step_type[i] = SWB_STEP_LAST;
+      if (discount) discount[i] = 0.0f;
+    } else {
+      if (step_type) step_type[i] = SWB_STEP_MID;
+      if (discount) discount[i] = 1.0f;
+    }
+  }
+  return 0;
+}
+
+int swo_render_range(swo_engine* e, int i0, int i1, uint8_t* obs) {
+  for (int i = i0; i < i1; ++i) observe(e, i, obs, NULL, NULL, NULL);
+  return 0;
+}
+
+int swo_get_state(swo_engine* e, const swb_state* st) {
+  const int N = e->cfg.n_envs, S = e->cfg.max_sprites;
+  if (st->x) memcpy(st->x, e->x, sizeof(double) * N * S);
+  if (st->y) memcpy(st->y, e->y, sizeof(double) * N * S);
+  if (st->n_sprites) memcpy(st->n_sprites, e->n, sizeof(int32_t) * N);
+  if (st->pool_entry) memcpy(st->pool_entry, e->entry, sizeof(int32_t) * N);
+  if (st->step_count) memcpy(st->step_count, e->step_count, sizeof(int32_t) * N);
+  if (st->reset_next) memcpy(st->reset_next, e->reset_next, N);
+  if (st->episode) memcpy(st->episode, e->episode, sizeof(int32_t) * N);
+  return 0;
+}
+
+int swo_set_positions(swo_engine* e, const double* x, const double* y) {
+  const int N = e->cfg.n_envs, S = e->cfg.max_sprites;
+  memcpy(e->x, x, sizeof(double) * N * S);
+  memcpy(e->y, y, sizeof(double) * N * S);
+  return 0;
+}
+
+/* Single frame without an engine (used by renderer parity tests). */
+int swo_render_sprites(const swb_config* cfg, int n, const double* x, const double* y,
+                       const int32_t* shape, const double* scale, const double* ca, const double* sa,
+                       const uint8_t* rgb, uint8_t* obs) {
+  render_env(cfg, n, x, y, shape, scale, ca, sa, rgb, obs);
+  return 0;
+}

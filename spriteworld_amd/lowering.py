@@ -1,0 +1,247 @@
+"""Lowering of reference-style Python objects to the C ABI (include/swb.h).
+
+The reference's configuration surface is duck-typed Python: `get_config()`
+returns {'task', 'action_space', 'renderers', 'init_sprites', ...} (reference:
+spriteworld/configs/cobra/goal_finding_more_distractors.py:41-96) and
+`Environment.__init__` just stores them (spriteworld/environment.py:34-72).
+This module reads the very attributes those objects set -- whether they are the
+reference's own classes or the mirrors in this package -- and produces
+
+  * `SwbConfig`   the flat struct consumed by `swb_create` (and by the oracle);
+  * `Pool`        a pool of initial states ("what init_sprites() returned"),
+                  with everything that is constant during an episode resolved
+                  on the host: cos/sin of the angle, RGB fill colour, and the
+                  task membership label of each sprite (tasks.py:134-137,
+                  196-205 evaluate `contains(sprite.factors)` every step, but
+                  `step()` only ever changes x and y, so for factor filters that
+                  do not key on x/y the result is fixed at reset).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from spriteworld_amd import _abi
+from spriteworld_amd import shapes as _shapes
+
+
+class LoweringError(ValueError):
+  pass
+
+
+def _cls(obj):
+  return type(obj).__name__
+
+
+# --------------------------------------------------------------------------- #
+# Config                                                                       #
+# --------------------------------------------------------------------------- #
+def _lower_task(task, out):
+  """Fills one SwbTask from a FindGoalPosition / Clustering / NoReward object."""
+  name = _cls(task)
+  if name == 'NoReward':
+    out.kind = _abi.TASK_NO_REWARD
+  elif name == 'FindGoalPosition':
+    out.kind = _abi.TASK_FIND_GOAL
+    goal = np.asarray(task._goal_position, dtype=np.float64)
+    weights = np.asarray(task._weights_dimensions, dtype=np.float64)
+    if goal.shape != (2,) or weights.shape != (2,):
+      raise LoweringError('goal_position / weights_dimensions must have 2 entries')
+    out.goal_position[0], out.goal_position[1] = goal
+    out.weights_dimensions[0], out.weights_dimensions[1] = weights
+    out.terminate_distance = float(task._terminate_distance)
+    out.raw_reward_multiplier = float(task._raw_reward_multiplier)
+    out.terminate_bonus = float(task._terminate_bonus)
+    out.sparse_reward = int(bool(task._sparse_reward))
+  elif name == 'Clustering':
+    out.kind = _abi.TASK_CLUSTERING
+    out.termination_threshold = float(task._termination_threshold)
+    out.terminate_bonus = float(task._terminate_bonus)
+    out.reward_range = float(task._reward_range)
+    out.sparse_reward = int(bool(task._sparse_reward))
+  else:
+    raise LoweringError('unsupported task type: ' + name)
+
+
+_AGG = {'nansum': _abi.AGG_SUM, 'nanmax': _abi.AGG_MAX, 'nanmin': _abi.AGG_MIN,
+        'nanmean': _abi.AGG_MEAN}
+_TERM = {'all': _abi.TERM_ALL, 'any': _abi.TERM_ANY}
+
+
+def subtasks_of(task):
+  """[sub-tasks] of a MetaAggregated task, or [task]."""
+  return list(task._subtasks) if _cls(task) == 'MetaAggregated' else [task]
+
+
+def find_pil_renderer(renderers):
+  """(name, renderer) of the PILRenderer in a `renderers` dict, or (None, None)."""
+  for name, r in renderers.items():
+    if hasattr(r, '_anti_aliasing') and hasattr(r, '_image_size'):
+      return name, r
+  return None, None
+
+
+def _bg_of(renderer):
+  if hasattr(renderer, '_bg_color'):
+    return tuple(int(v) for v in renderer._bg_color)
+  return tuple(int(v) for v in renderer._canvas_bg.getpixel((0, 0)))  # reference PILRenderer
+
+
+def lower_config(task, action_space, renderers, keep_in_frame=True, max_episode_length=1000,
+                 num_envs=1, max_sprites=1, pos_is_f32=True):
+  """Builds the SwbConfig for Environment(task, action_space, renderers, ...)."""
+  cfg = _abi.SwbConfig()
+  cfg.n_envs = int(num_envs)
+  cfg.max_sprites = int(max_sprites)
+  if not 1 <= cfg.max_sprites <= _abi.SWB_MAX_SPRITES:
+    raise LoweringError('max_sprites must be in [1, %d]' % _abi.SWB_MAX_SPRITES)
+  _, pil = find_pil_renderer(renderers)
+  if pil is None:  # e.g. tests/configs_test.py builds environments with renderers={}
+    cfg.image_h, cfg.image_w, cfg.anti_aliasing = 8, 8, 1
+  else:
+    cfg.image_h, cfg.image_w = int(pil._image_size[0]), int(pil._image_size[1])
+    cfg.anti_aliasing = int(pil._anti_aliasing)
+    for i, v in enumerate(_bg_of(pil)[:3]):
+      cfg.bg_rgb[i] = v
+  # action space
+  name = _cls(action_space)
+  if name in ('SelectMove', 'DragAndDrop'):
+    cfg.action_space = (_abi.ACTION_SELECT_MOVE if name == 'SelectMove' else
+                        _abi.ACTION_DRAG_AND_DROP)
+    cfg.action_scale = float(action_space._scale)
+    cfg.motion_cost = float(action_space._motion_cost)
+    if getattr(action_space, '_noise_scale', None):
+      raise LoweringError('SelectMove noise_scale is applied by the caller: pass pre-noised '
+                          'actions (see DESIGN.md, out-of-scope list)')
+  elif name == 'Embodied':
+    cfg.action_space = _abi.ACTION_EMBODIED
+    cfg.action_scale = float(action_space._step_size)
+    cfg.motion_cost = float(action_space._motion_cost)
+  else:
+    raise LoweringError('unsupported action space: ' + name)
+  cfg.keep_in_frame = int(bool(keep_in_frame))
+  cfg.max_episode_length = int(max_episode_length)
+  cfg.pos_is_f32 = int(bool(pos_is_f32))
+  # task(s)
+  subs = subtasks_of(task)
+  if not 1 <= len(subs) <= _abi.SWB_MAX_TASKS:
+    raise LoweringError('between 1 and %d sub-tasks supported' % _abi.SWB_MAX_TASKS)
+  cfg.n_tasks = len(subs)
+  if _cls(task) == 'MetaAggregated':
+    cfg.is_meta = 1
+    agg = getattr(task._reward_aggregator, '__name__', '')
+    term = getattr(task._termination_criterion, '__name__', '')
+    if agg not in _AGG or term not in _TERM:
+      raise LoweringError('unknown MetaAggregated aggregator/criterion: %s/%s' % (agg, term))
+    cfg.meta_aggregator, cfg.meta_termination = _AGG[agg], _TERM[term]
+    cfg.meta_terminate_bonus = float(task._terminate_bonus)
+  for i, sub in enumerate(subs):
+    _lower_task(sub, cfg.tasks[i])
+  return cfg
+
+
+# --------------------------------------------------------------------------- #
+# Pool                                                                         #
+# --------------------------------------------------------------------------- #
+class Pool(object):
+  """Host arrays of a reset pool (layout of `swb_pool`, include/swb.h)."""
+
+  FIELDS = ('n_sprites', 'x', 'y', 'x_vel', 'y_vel', 'scale', 'cos_a', 'sin_a', 'shape', 'rgb',
+            'label', 'pool_base', 'pool_len')
+
+  def __init__(self, n_entries, max_sprites, n_tasks):
+    P, S, T = int(n_entries), int(max_sprites), int(n_tasks)
+    self.n_entries, self.max_sprites, self.n_tasks = P, S, T
+    self.n_sprites = np.zeros(P, np.int32)
+    for name in ('x', 'y', 'x_vel', 'y_vel', 'scale', 'cos_a', 'sin_a'):
+      setattr(self, name, np.zeros((P, S), np.float64))
+    self.scale[:] = 1.0
+    self.cos_a[:] = 1.0
+    self.shape = np.zeros((P, S), np.int32)
+    self.rgb = np.zeros((P, S, 4), np.uint8)
+    self.label = np.zeros((P, T, S), np.int8)
+    self.pool_base = None
+    self.pool_len = None
+    # Not consumed by the kernels; kept for SpriteFactors-style observations.
+    self.angle = np.zeros((P, S), np.float64)
+    self.color = np.zeros((P, S, 3), np.float64)
+
+  def assign_round_robin(self, num_envs, entries_per_env=None):
+    """Env n draws entries [n*k, (n+1)*k) cyclically (k = P // num_envs)."""
+    k = entries_per_env or max(self.n_entries // num_envs, 1)
+    if k * num_envs > self.n_entries and entries_per_env:
+      raise LoweringError('pool too small for %d envs x %d entries' % (num_envs, k))
+    self.pool_base = ((np.arange(num_envs, dtype=np.int64) * k) % max(self.n_entries - k + 1, 1)
+                      ).astype(np.int32)
+    self.pool_len = np.full(num_envs, k, np.int32)
+    return self
+
+  def as_struct(self):
+    if self.pool_base is None:
+      raise LoweringError('pool has no env assignment (call assign_round_robin)')
+    for name in self.FIELDS:
+      a = getattr(self, name)
+      if not a.flags['C_CONTIGUOUS']:
+        setattr(self, name, np.ascontiguousarray(a))
+    s = _abi.SwbPool()
+    s.n_entries = self.n_entries
+    for name in self.FIELDS:
+      setattr(s, name, getattr(self, name).ctypes.data)
+    return s
+
+
+def _label_of(sub, sprite):
+  name = _cls(sub)
+  if name == 'FindGoalPosition':
+    f = sub._filter_distrib
+    return int(f is None or bool(f.contains(sprite.factors)))
+  if name == 'Clustering':
+    for ci, distrib in enumerate(sub._cluster_distribs):
+      if distrib.contains(sprite.factors):
+        return ci
+    return -1
+  return 0
+
+
+def position_dtype(episodes):
+  """np.float32 / np.float64: dtype of the sprites' position arrays (must agree)."""
+  kinds = set()
+  for ep in episodes:
+    for s in ep:
+      kinds.add(np.asarray(s.position).dtype)
+  if not kinds:
+    return np.dtype(np.float32)
+  if len(kinds) > 1:
+    raise LoweringError('sprites mix position dtypes %s' % sorted(map(str, kinds)))
+  dt = kinds.pop()
+  if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+    raise LoweringError('unsupported position dtype %s' % dt)
+  return dt
+
+
+def lower_episodes(episodes, task, renderers, max_sprites=None):
+  """List of sprite lists (one per reset, back-to-front order) -> Pool."""
+  subs = subtasks_of(task)
+  _, pil = find_pil_renderer(renderers)
+  to_rgb = pil._color_to_rgb if pil is not None else (lambda c: (0, 0, 0))
+  S = max_sprites or max([len(ep) for ep in episodes] + [1])
+  pool = Pool(len(episodes), S, len(subs))
+  for e, ep in enumerate(episodes):
+    if len(ep) > S:
+      raise LoweringError('episode %d has %d sprites > max_sprites %d' % (e, len(ep), S))
+    pool.n_sprites[e] = len(ep)
+    for s, sp in enumerate(ep):
+      pos = np.asarray(sp.position)
+      pool.x[e, s], pool.y[e, s] = float(pos[0]), float(pos[1])
+      pool.x_vel[e, s], pool.y_vel[e, s] = float(sp.velocity[0]), float(sp.velocity[1])
+      pool.scale[e, s] = float(sp.scale)
+      theta = math.radians(sp.angle)  # matplotlib Affine2D.rotate_deg
+      pool.cos_a[e, s], pool.sin_a[e, s] = math.cos(theta), math.sin(theta)
+      pool.angle[e, s] = float(sp.angle)
+      pool.shape[e, s] = _shapes.shape_index(sp.shape)
+      rgb = to_rgb(sp.color)
+      pool.rgb[e, s, :3] = np.asarray(rgb).astype(np.uint8)
+      pool.color[e, s] = [float(c) for c in sp.color]
+      for t, sub in enumerate(subs):
+        pool.label[e, t, s] = _label_of(sub, sp)
+  return pool
