@@ -1,0 +1,25 @@
+"""Builds the HIP engine in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+SOURCES = ('swb.hip', 'swb_kernels.hip.inc', 'swb_pow.hip.inc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
+         '-shared', '-fPIC']
+
+
+def build(force=False, verbose=False):
+  out = os.path.join(CSRC, 'libswb.so')
+  deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(_HERE, '..', 'include', 'swb.h')]
+  if (not force and os.path.exists(out) and
+      os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps)):
+    return out
+  hipcc = os.environ.get('HIPCC', 'hipcc')
+  if not any(os.access(os.path.join(d, hipcc), os.X_OK) for d in os.environ['PATH'].split(':')):
+    hipcc = '/opt/rocm/bin/hipcc'
+  cmd = [hipcc] + FLAGS + ['-o', out, os.path.join(CSRC, 'swb.hip')]
+  if verbose:
+    print(' '.join(cmd))
+  subprocess.check_call(cmd, cwd=CSRC)
+  return out

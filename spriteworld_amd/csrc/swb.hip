@@ -1,0 +1,413 @@
+// swb.hip -- C-ABI host side of the batched Spriteworld engine (see include/swb.h).
+//
+// Owns the device copies of the constant tables, the reset pool and the live
+// structure-of-arrays state; launches the fused step kernel (swb_kernels.hip.inc).
+// Built only for gfx950:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "swb_kernels.hip.inc"
+#include "swb_pow.hip.inc"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(SWB_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+int upload(T** dst, const T* src, size_t count) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  if (count == 0) count = 1;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), count * sizeof(T)));
+  if (src) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemset(*dst, 0, count * sizeof(T)));
+  return 0;
+}
+
+}  // namespace
+
+struct swb_engine {
+  swb_config cfg;
+  int device = 0;
+  swb_params p;        // device pointers + config, passed by value to the kernel
+  bool have_shapes = false, have_h = false, have_v = false, have_pool = false;
+  int nw = 0, ncol = 0;
+  size_t lds_block = 0;
+  // owned device buffers
+  double* d_shape_verts = nullptr;
+  int32_t* d_shape_off = nullptr;
+  int32_t *d_h_xmin = nullptr, *d_h_cnt = nullptr, *d_h_tbl = nullptr, *d_h_pfx = nullptr;
+  int32_t *d_v_tab = nullptr, *d_v_end = nullptr;
+  int32_t* d_p_n = nullptr;
+  double *d_p_x = nullptr, *d_p_y = nullptr, *d_p_xv = nullptr, *d_p_yv = nullptr, *d_p_scale = nullptr,
+         *d_p_ca = nullptr, *d_p_sa = nullptr;
+  int32_t* d_p_shape = nullptr;
+  uint32_t* d_p_rgb = nullptr;
+  int8_t* d_p_label = nullptr;
+  int32_t *d_pool_base = nullptr, *d_pool_len = nullptr;
+  double *d_x = nullptr, *d_y = nullptr;
+  int32_t *d_nspr = nullptr, *d_entry = nullptr, *d_step_count = nullptr, *d_episode = nullptr;
+  uint8_t* d_reset_next = nullptr;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double timed_ms = 0.0;
+  int64_t timed_launches = 0;
+};
+
+namespace {
+
+typedef void (*kernel_fn)(const swb_params);
+
+struct variant { int nw, ncol; kernel_fn fn; size_t lds_fixed; };
+
+template <int NW, int NCOL>
+variant make_variant() {
+  return {NW, NCOL, swb_step_kernel<NW, NCOL>, (sizeof(wave_lds<NW>) + 15) & ~(size_t)15};
+}
+
+// canvas widths up to 32*NW pixels, image widths up to 64*NCOL pixels
+const variant kVariants[] = {
+    make_variant<2, 1>(),  make_variant<4, 1>(),  make_variant<4, 2>(),  make_variant<5, 1>(),
+    make_variant<10, 1>(), make_variant<10, 2>(), make_variant<20, 2>(), make_variant<20, 4>(),
+};
+
+const variant* pick_variant(int Wc, int Wo) {
+  for (const variant& v : kVariants)
+    if (32 * v.nw >= Wc && 64 * v.ncol >= Wo) return &v;
+  return nullptr;
+}
+
+int flush_timing(swb_engine* h) {
+  for (auto& ev : h->events) {
+    HIP_TRY(hipEventSynchronize(ev.second));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+    h->timed_ms += ms;
+    h->timed_launches += 1;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  h->events.clear();
+  return 0;
+}
+
+int launch(swb_engine* h, const void* actions, const swb_outputs* out, int render_only, hipStream_t stream) {
+  if (!h->have_shapes) return fail(SWB_ERR_STATE, "swb_upload_shapes has not been called");
+  if (!h->have_pool) return fail(SWB_ERR_STATE, "swb_set_pool has not been called");
+  const swb_config& c = h->cfg;
+  if (c.anti_aliasing != 1 && !(h->have_h && h->have_v))
+    return fail(SWB_ERR_STATE, "swb_upload_resample (both axes) is required when anti_aliasing > 1");
+  const variant* v = pick_variant(h->p.Wc, h->p.Wo);
+  if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d / image width %d not supported", h->p.Wc, h->p.Hc, h->p.Wo);
+  swb_params p = h->p;
+  p.actions = actions;
+  p.obs = out ? out->obs : nullptr;
+  p.reward = out ? out->reward : nullptr;
+  p.discount = out ? out->discount : nullptr;
+  p.step_type = out ? out->step_type : nullptr;
+  p.success = out ? out->success : nullptr;
+  p.error = out ? out->error : nullptr;
+  p.render_only = render_only;
+  if (!render_only && actions == nullptr) return fail(SWB_ERR_INVALID, "actions is NULL");
+  const size_t pfx_bytes = ((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15;
+  const size_t per_wave = (v->lds_fixed + (size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15;
+  p.lds_per_wave = (int32_t)per_wave;
+  const size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
+  if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(v->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int blocks = (c.n_envs + SWB_WAVES_PER_BLOCK - 1) / SWB_WAVES_PER_BLOCK;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->timing) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+  }
+  hipLaunchKernelGGL(v->fn, dim3(blocks), dim3(SWB_WAVE * SWB_WAVES_PER_BLOCK), lds, stream, p);
+  HIP_TRY(hipGetLastError());
+  if (h->timing) {
+    HIP_TRY(hipEventRecord(e1, stream));
+    h->events.emplace_back(e0, e1);
+    if (h->events.size() >= 4096) return flush_timing(h);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* swb_last_error(void) { return g_err.c_str(); }
+int swb_version(void) { return 1; }
+
+int swb_create(const swb_config* cfg, int device, swb_handle* out) {
+  if (!cfg || !out) return fail(SWB_ERR_INVALID, "null argument");
+  if (cfg->n_envs < 1) return fail(SWB_ERR_INVALID, "n_envs must be >= 1");
+  if (cfg->max_sprites < 1 || cfg->max_sprites > SWB_MAX_SPRITES)
+    return fail(SWB_ERR_INVALID, "max_sprites must be in [1, %d]", SWB_MAX_SPRITES);
+  if (cfg->n_tasks < 1 || cfg->n_tasks > SWB_MAX_TASKS) return fail(SWB_ERR_INVALID, "n_tasks must be in [1, %d]", SWB_MAX_TASKS);
+  if (cfg->anti_aliasing < 1) return fail(SWB_ERR_INVALID, "anti_aliasing must be >= 1");
+  if (cfg->image_h < 1 || cfg->image_w < 1 || (cfg->image_h % 4) != 0)
+    return fail(SWB_ERR_INVALID, "image_size[0] must be a positive multiple of 4");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SWB_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(SWB_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SWB_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  swb_engine* h = new swb_engine();
+  h->cfg = *cfg;
+  h->device = device;
+  swb_params& p = h->p;
+  memset(&p, 0, sizeof(p));
+  p.N = cfg->n_envs; p.S = cfg->max_sprites; p.AA = cfg->anti_aliasing;
+  // The reference makes the PIL canvas of *size* (AA*image_size[0], AA*image_size[1]) = (width, height)
+  // (pil_renderer.py:50-51,64); np.array(image) is then [image_size[1], image_size[0], 3].
+  p.Wo = cfg->image_h; p.Ho = cfg->image_w;
+  p.Wc = p.AA * p.Wo; p.Hc = p.AA * p.Ho;
+  p.bg = (uint32_t)cfg->bg_rgb[0] | ((uint32_t)cfg->bg_rgb[1] << 8) | ((uint32_t)cfg->bg_rgb[2] << 16);
+  p.action_space = cfg->action_space; p.keep_in_frame = cfg->keep_in_frame;
+  p.max_episode_length = cfg->max_episode_length; p.pos_is_f32 = cfg->pos_is_f32;
+  p.action_scale = cfg->action_scale; p.motion_cost = cfg->motion_cost;
+  p.n_tasks = cfg->n_tasks; p.is_meta = cfg->is_meta; p.meta_aggregator = cfg->meta_aggregator;
+  p.meta_termination = cfg->meta_termination; p.meta_terminate_bonus = cfg->meta_terminate_bonus;
+  memcpy(p.tasks, cfg->tasks, sizeof(p.tasks));
+  if (p.Wc > 1023 || p.Hc > 65535) { delete h; return fail(SWB_ERR_INVALID, "canvas %dx%d too large", p.Wc, p.Hc); }
+  if (!pick_variant(p.Wc, p.Wo)) { delete h; return fail(SWB_ERR_INVALID, "canvas width %d / image width %d not supported", p.Wc, p.Wo); }
+  const size_t NS = (size_t)p.N * p.S;
+  int rc = 0;
+  rc |= upload(&h->d_x, (const double*)nullptr, NS);
+  rc |= upload(&h->d_y, (const double*)nullptr, NS);
+  rc |= upload(&h->d_nspr, (const int32_t*)nullptr, p.N);
+  rc |= upload(&h->d_entry, (const int32_t*)nullptr, p.N);
+  rc |= upload(&h->d_step_count, (const int32_t*)nullptr, p.N);
+  rc |= upload(&h->d_episode, (const int32_t*)nullptr, p.N);
+  rc |= upload(&h->d_reset_next, (const uint8_t*)nullptr, p.N);
+  if (rc) { swb_destroy(h); return SWB_ERR_HIP; }
+  p.x = h->d_x; p.y = h->d_y; p.nspr = h->d_nspr; p.entry = h->d_entry; p.step_count = h->d_step_count;
+  p.episode = h->d_episode; p.reset_next = h->d_reset_next;
+  *out = h;
+  return SWB_OK;
+}
+
+int swb_destroy(swb_handle h) {
+  if (!h) return SWB_OK;
+  (void)hipSetDevice(h->device);
+  for (auto& ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  void* bufs[] = {h->d_shape_verts, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
+                  h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
+                  h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
+                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  delete h;
+  return SWB_OK;
+}
+
+int swb_upload_shapes(swb_handle h, const double* verts, const int32_t* offsets, int32_t n_shapes) {
+  if (!h || !verts || !offsets) return fail(SWB_ERR_INVALID, "null argument");
+  if (n_shapes < 1 || n_shapes > SWB_MAX_SHAPES) return fail(SWB_ERR_INVALID, "n_shapes must be in [1, %d]", SWB_MAX_SHAPES);
+  HIP_TRY(hipSetDevice(h->device));
+  int maxv = 0;
+  for (int i = 0; i < n_shapes; ++i) {
+    const int n = offsets[i + 1] - offsets[i];
+    if (n < 3 || n > SWB_MAX_SHAPE_VERTS) return fail(SWB_ERR_INVALID, "shape %d has %d vertices (3..%d supported)", i, n, SWB_MAX_SHAPE_VERTS);
+    if (n > maxv) maxv = n;
+  }
+  if (upload(&h->d_shape_verts, verts, (size_t)offsets[n_shapes] * 2)) return SWB_ERR_HIP;
+  if (upload(&h->d_shape_off, offsets, (size_t)n_shapes + 1)) return SWB_ERR_HIP;
+  h->p.shape_verts = h->d_shape_verts;
+  h->p.shape_off = h->d_shape_off;
+  h->p.max_verts = maxv;
+  h->p.max_edges = maxv * h->p.S;
+  h->have_shapes = true;
+  return SWB_OK;
+}
+
+int swb_upload_resample(swb_handle h, int32_t axis, int32_t out_size, int32_t ksize, const int32_t* bounds,
+                        const int32_t* coeffs) {
+  if (!h || !bounds || !coeffs) return fail(SWB_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const swb_params& p = h->p;
+  if (axis == 0) {
+    if (out_size != p.Wo) return fail(SWB_ERR_INVALID, "horizontal table has %d outputs, image width is %d", out_size, p.Wo);
+    // prefix sums, de-duplicated: the interior columns share one vector
+    std::vector<int32_t> xmin(out_size), cnt(out_size), tbl(out_size), pfx;
+    std::vector<std::vector<int32_t>> uniq;
+    std::vector<int32_t> uniq_off;
+    for (int o = 0; o < out_size; ++o) {
+      xmin[o] = bounds[2 * o]; cnt[o] = bounds[2 * o + 1];
+      if (cnt[o] < 0 || cnt[o] > ksize || xmin[o] < 0 || xmin[o] + cnt[o] > p.Wc)
+        return fail(SWB_ERR_INVALID, "bad horizontal bounds at %d", o);
+      std::vector<int32_t> v(cnt[o] + 1, 0);
+      for (int j = 0; j < cnt[o]; ++j) v[j + 1] = v[j] + coeffs[(size_t)o * ksize + j];
+      int found = -1;
+      for (size_t u = 0; u < uniq.size(); ++u) if (uniq[u] == v) { found = (int)u; break; }
+      if (found < 0) { found = (int)uniq.size(); uniq.push_back(v); uniq_off.push_back((int32_t)pfx.size()); pfx.insert(pfx.end(), v.begin(), v.end()); }
+      tbl[o] = uniq_off[found];
+    }
+    if (pfx.size() * 4 > 32 * 1024) return fail(SWB_ERR_INVALID, "horizontal prefix table too large (%zu entries)", pfx.size());
+    if (upload(&h->d_h_xmin, xmin.data(), xmin.size()) || upload(&h->d_h_cnt, cnt.data(), cnt.size()) ||
+        upload(&h->d_h_tbl, tbl.data(), tbl.size()) || upload(&h->d_h_pfx, pfx.data(), pfx.size()))
+      return SWB_ERR_HIP;
+    h->p.h_xmin = h->d_h_xmin; h->p.h_cnt = h->d_h_cnt; h->p.h_tbl = h->d_h_tbl; h->p.h_pfx = h->d_h_pfx;
+    h->p.h_pfx_len = (int32_t)pfx.size();
+    h->have_h = true;
+  } else if (axis == 1) {
+    if (out_size != p.Ho) return fail(SWB_ERR_INVALID, "vertical table has %d outputs, image height is %d", out_size, p.Ho);
+    std::vector<int32_t> vend(out_size), vtab((size_t)p.Hc * SWB_VSLOTS, 0);
+    for (int r = 0; r < out_size; ++r) {
+      const int ymin = bounds[2 * r], c = bounds[2 * r + 1];
+      if (c < 1 || c > ksize || ymin < 0 || ymin + c > p.Hc) return fail(SWB_ERR_INVALID, "bad vertical bounds at %d", r);
+      vend[r] = ymin + c - 1;
+      if (r > 0 && (vend[r] < vend[r - 1] || ymin < bounds[2 * (r - 1)])) return fail(SWB_ERR_INVALID, "vertical windows are not monotone");
+    }
+    for (int y = 0; y < p.Hc; ++y) {
+      int rf = 0;
+      while (rf < out_size && vend[rf] < y) ++rf;     // rows completed before canvas row y
+      for (int r = 0; r < out_size; ++r) {
+        const int ymin = bounds[2 * r];
+        if (y < ymin || y > vend[r]) continue;
+        const int k = r - rf;
+        if (k < 0 || k >= SWB_VSLOTS) return fail(SWB_ERR_INVALID, "more than %d output rows in flight at canvas row %d", SWB_VSLOTS, y);
+        vtab[(size_t)y * SWB_VSLOTS + k] = coeffs[(size_t)r * ksize + (y - ymin)];
+      }
+    }
+    if (upload(&h->d_v_tab, vtab.data(), vtab.size()) || upload(&h->d_v_end, vend.data(), vend.size())) return SWB_ERR_HIP;
+    h->p.v_tab = h->d_v_tab; h->p.v_end = h->d_v_end;
+    h->have_v = true;
+  } else {
+    return fail(SWB_ERR_INVALID, "axis must be 0 or 1");
+  }
+  return SWB_OK;
+}
+
+int swb_set_pool(swb_handle h, const swb_pool* pool) {
+  if (!h || !pool) return fail(SWB_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const int P = pool->n_entries, S = h->p.S, T = h->p.n_tasks, N = h->p.N;
+  if (P < 1) return fail(SWB_ERR_INVALID, "pool is empty");
+  for (int i = 0; i < P; ++i)
+    if (pool->n_sprites[i] < 0 || pool->n_sprites[i] > S) return fail(SWB_ERR_INVALID, "pool entry %d has %d sprites (max %d)", i, pool->n_sprites[i], S);
+  for (int i = 0; i < N; ++i)
+    if (pool->pool_len[i] < 1 || pool->pool_base[i] < 0 || pool->pool_base[i] + pool->pool_len[i] > P)
+      return fail(SWB_ERR_INVALID, "env %d: pool range [%d, +%d) outside the pool of %d", i, pool->pool_base[i], pool->pool_len[i], P);
+  const size_t PS = (size_t)P * S;
+  std::vector<uint32_t> rgb(PS);
+  for (size_t i = 0; i < PS; ++i)
+    rgb[i] = (uint32_t)pool->rgb[4 * i] | ((uint32_t)pool->rgb[4 * i + 1] << 8) | ((uint32_t)pool->rgb[4 * i + 2] << 16);
+  for (size_t i = 0; i < PS; ++i)
+    if (pool->shape[i] < 0 || (h->have_shapes && pool->shape[i] >= SWB_MAX_SHAPES)) return fail(SWB_ERR_INVALID, "bad shape index in pool");
+  int rc = 0;
+  rc |= upload(&h->d_p_n, pool->n_sprites, P);
+  rc |= upload(&h->d_p_x, pool->x, PS); rc |= upload(&h->d_p_y, pool->y, PS);
+  rc |= upload(&h->d_p_xv, pool->x_vel, PS); rc |= upload(&h->d_p_yv, pool->y_vel, PS);
+  rc |= upload(&h->d_p_scale, pool->scale, PS); rc |= upload(&h->d_p_ca, pool->cos_a, PS); rc |= upload(&h->d_p_sa, pool->sin_a, PS);
+  rc |= upload(&h->d_p_shape, pool->shape, PS);
+  rc |= upload(&h->d_p_rgb, rgb.data(), PS);
+  rc |= upload(&h->d_p_label, pool->label, (size_t)P * T * S);
+  rc |= upload(&h->d_pool_base, pool->pool_base, N);
+  rc |= upload(&h->d_pool_len, pool->pool_len, N);
+  if (rc) return SWB_ERR_HIP;
+  swb_params& p = h->p;
+  p.p_n = h->d_p_n; p.p_x = h->d_p_x; p.p_y = h->d_p_y; p.p_xv = h->d_p_xv; p.p_yv = h->d_p_yv;
+  p.p_scale = h->d_p_scale; p.p_ca = h->d_p_ca; p.p_sa = h->d_p_sa; p.p_shape = h->d_p_shape; p.p_rgb = h->d_p_rgb;
+  p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
+  HIP_TRY(hipMemset(h->d_reset_next, 1, N));      // environment.py:70
+  HIP_TRY(hipMemset(h->d_episode, 0, sizeof(int32_t) * N));
+  HIP_TRY(hipMemset(h->d_step_count, 0, sizeof(int32_t) * N));
+  h->have_pool = true;
+  return SWB_OK;
+}
+
+int swb_reset_all(swb_handle h, void* stream) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemsetAsync(h->d_reset_next, 1, h->p.N, (hipStream_t)stream));
+  return SWB_OK;
+}
+
+int swb_step(swb_handle h, const void* actions_dev, const swb_outputs* out, void* stream) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  return launch(h, actions_dev, out, 0, (hipStream_t)stream);
+}
+
+int swb_render(swb_handle h, uint8_t* obs_dev, void* stream) {
+  if (!h || !obs_dev) return fail(SWB_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  swb_outputs out;
+  memset(&out, 0, sizeof(out));
+  out.obs = obs_dev;
+  return launch(h, nullptr, &out, 1, (hipStream_t)stream);
+}
+
+int swb_get_state(swb_handle h, const swb_state* st, void* stream) {
+  if (!h || !st) return fail(SWB_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  const size_t N = h->p.N, NS = N * h->p.S;
+  if (st->x) HIP_TRY(hipMemcpy(st->x, h->d_x, NS * 8, hipMemcpyDeviceToHost));
+  if (st->y) HIP_TRY(hipMemcpy(st->y, h->d_y, NS * 8, hipMemcpyDeviceToHost));
+  if (st->n_sprites) HIP_TRY(hipMemcpy(st->n_sprites, h->d_nspr, N * 4, hipMemcpyDeviceToHost));
+  if (st->pool_entry) HIP_TRY(hipMemcpy(st->pool_entry, h->d_entry, N * 4, hipMemcpyDeviceToHost));
+  if (st->step_count) HIP_TRY(hipMemcpy(st->step_count, h->d_step_count, N * 4, hipMemcpyDeviceToHost));
+  if (st->reset_next) HIP_TRY(hipMemcpy(st->reset_next, h->d_reset_next, N, hipMemcpyDeviceToHost));
+  if (st->episode) HIP_TRY(hipMemcpy(st->episode, h->d_episode, N * 4, hipMemcpyDeviceToHost));
+  return SWB_OK;
+}
+
+int swb_set_positions(swb_handle h, const double* x_host, const double* y_host, void* stream) {
+  if (!h || !x_host || !y_host) return fail(SWB_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  const size_t NS = (size_t)h->p.N * h->p.S;
+  HIP_TRY(hipMemcpy(h->d_x, x_host, NS * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_y, y_host, NS * 8, hipMemcpyHostToDevice));
+  return SWB_OK;
+}
+
+int swb_timing_enable(swb_handle h, int32_t enable) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if (flush_timing(h)) return SWB_ERR_HIP;
+  h->timing = enable != 0;
+  h->timed_ms = 0.0;
+  h->timed_launches = 0;
+  return SWB_OK;
+}
+
+int swb_step_time_ms(swb_handle h, double* total_ms, int64_t* launches) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if (flush_timing(h)) return SWB_ERR_HIP;
+  if (total_ms) *total_ms = h->timed_ms;
+  if (launches) *launches = h->timed_launches;
+  return SWB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+"""Thin Python handle on the HIP engine: device buffers are torch tensors.
+
+PyTorch is used here for device memory and streams only; all computation is in
+libswb.so.  One `Engine` = one `swb_handle` = N environments on one GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from spriteworld_amd import _abi
+from spriteworld_amd import _lib
+from spriteworld_amd import lanczos
+from spriteworld_amd import shapes as _shapes
+
+
+def _ptr(a):
+  return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Engine(object):
+  """N batched environments on one MI355X (`cfg`: _abi.SwbConfig, `pool`: lowering.Pool)."""
+
+  def __init__(self, cfg, pool, device=0):
+    if not torch.cuda.is_available():
+      raise _lib.SwbError('no GPU visible: the Spriteworld engine has no CPU path')
+    self.lib = _lib.load()
+    self.cfg = cfg
+    self.device = torch.device('cuda', device)
+    self.N, self.S = cfg.n_envs, cfg.max_sprites
+    # the reference's np.array(image) is [image_size[1], image_size[0], 3]
+    self.obs_shape = (cfg.image_w, cfg.image_h, 3)
+    h = C.c_void_p()
+    _lib.check(self.lib.swb_create(C.byref(cfg), device, C.byref(h)))
+    self._h = h
+    verts, offs = _shapes.packed_table()
+    _lib.check(self.lib.swb_upload_shapes(self._h, _ptr(verts), _ptr(offs), len(offs) - 1))
+    aa = cfg.anti_aliasing
+    if aa != 1:
+      for axis, out_size in ((0, cfg.image_h), (1, cfg.image_w)):
+        bounds, coeffs = lanczos.resample_tables(aa * out_size, out_size)
+        bounds = np.ascontiguousarray(bounds)
+        coeffs = np.ascontiguousarray(coeffs)
+        _lib.check(self.lib.swb_upload_resample(self._h, axis, out_size, coeffs.shape[1],
+                                                _ptr(bounds), _ptr(coeffs)))
+    self.set_pool(pool)
+    with torch.cuda.device(self.device):
+      self.obs = torch.zeros((self.N,) + self.obs_shape, dtype=torch.uint8, device=self.device)
+      self.reward = torch.zeros(self.N, dtype=torch.float64, device=self.device)
+      self.discount = torch.zeros(self.N, dtype=torch.float32, device=self.device)
+      self.step_type = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+      self.success = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+      self.error = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
+    self._outs = self._make_outs(render=True)
+    self._outs_norender = self._make_outs(render=False)
+
+  def _make_outs(self, render):
+    o = _abi.SwbOutputs()
+    o.obs = self.obs.data_ptr() if render else None
+    o.reward = self.reward.data_ptr()
+    o.discount = self.discount.data_ptr()
+    o.step_type = self.step_type.data_ptr()
+    o.success = self.success.data_ptr()
+    o.error = self.error.data_ptr()
+    return o
+
+  def close(self):
+    if getattr(self, '_h', None):
+      torch.cuda.synchronize(self.device)
+      self.lib.swb_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def _stream(self):
+    return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+  def set_pool(self, pool):
+    self.pool = pool
+    cpool = pool.as_struct()
+    _lib.check(self.lib.swb_set_pool(self._h, C.byref(cpool)))
+
+  def reset_all(self):
+    _lib.check(self.lib.swb_reset_all(self._h, self._stream()))
+
+  def step(self, actions, render=True):
+    """actions: device tensor f64[N,4] (SelectMove/DragAndDrop) or i32[N,2] (Embodied)."""
+    want = torch.int32 if self.cfg.action_space == _abi.ACTION_EMBODIED else torch.float64
+    if not isinstance(actions, torch.Tensor):
+      actions = torch.as_tensor(np.ascontiguousarray(actions), device=self.device)
+    if actions.dtype != want or actions.device != self.device or not actions.is_contiguous():
+      actions = actions.to(device=self.device, dtype=want).contiguous()
+    assert actions.numel() == self.N * (2 if want == torch.int32 else 4), actions.shape
+    self._last_actions = actions  # keep alive until the launch is consumed
+    outs = self._outs if render else self._outs_norender
+    _lib.check(self.lib.swb_step(self._h, C.c_void_p(actions.data_ptr()), C.byref(outs),
+                                 self._stream()))
+
+  def render(self):
+    _lib.check(self.lib.swb_render(self._h, C.c_void_p(self.obs.data_ptr()), self._stream()))
+    return self.obs
+
+  def state(self):
+    st = {
+        'x': np.zeros((self.N, self.S)), 'y': np.zeros((self.N, self.S)),
+        'n_sprites': np.zeros(self.N, np.int32), 'pool_entry': np.zeros(self.N, np.int32),
+        'step_count': np.zeros(self.N, np.int32), 'reset_next': np.zeros(self.N, np.uint8),
+        'episode': np.zeros(self.N, np.int32),
+    }
+    cs = _abi.SwbState(*[a.ctypes.data for a in (st['x'], st['y'], st['n_sprites'], st['pool_entry'],
+                                                  st['step_count'], st['reset_next'], st['episode'])])
+    _lib.check(self.lib.swb_get_state(self._h, C.byref(cs), self._stream()))
+    return st
+
+  def set_positions(self, x, y):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    _lib.check(self.lib.swb_set_positions(self._h, _ptr(x), _ptr(y), self._stream()))
+
+  def outputs_host(self):
+    torch.cuda.synchronize(self.device)
+    return {
+        'obs': self.obs.cpu().numpy(), 'reward': self.reward.cpu().numpy(),
+        'discount': self.discount.cpu().numpy(), 'step_type': self.step_type.cpu().numpy(),
+        'success': self.success.cpu().numpy(), 'error': self.error.cpu().numpy(),
+    }
+
+  def timing(self, enable):
+    _lib.check(self.lib.swb_timing_enable(self._h, int(enable)))
+
+  def step_time_ms(self):
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    _lib.check(self.lib.swb_step_time_ms(self._h, C.byref(ms), C.byref(n)))
+    return ms.value, n.value

@@ -1,0 +1,89 @@
+"""The BASELINE.json workloads as concrete (config, pool, action sampler) triples.
+
+Each workload is the batched form of a reference configuration (SURVEY.md
+section 8d concretises BASELINE.json's `configs`):
+
+  goal_s5      1024/8192 envs, 5 sprites (2 targets + 3 distractors),
+               SelectMove(scale 0.25), FindGoalPosition(filter c0 in [0, 0.4),
+               terminate_distance 0.075), 64x64 AA=5 HSV, episodes of 20 steps
+               (reference: configs/cobra/goal_finding_more_distractors.py:54-96,
+               configs/cobra/common.py:26-38)
+  cluster_s5   8192 envs, 5 sprites in 2 hue clusters (2 'blue' + 3 'green'),
+               Clustering(threshold 2.5, reward_range 10), episodes of 50 steps
+               (reference: configs/cobra/clustering.py:41-46,71-109)   <- headline
+  embodied_s12 8192 envs, 11 sprites + body circle (scale 0.07), Embodied(step
+               0.05), FindGoalPosition, 128x128 AA=5
+               (reference: configs/examples/goal_finding_embodied.py:47-118)
+  sorting_s4   MetaAggregated of FindGoalPosition sub-tasks
+               (reference: configs/cobra/sorting.py:41-140)
+
+All use synthetic pools drawn with numpy (spriteworld_amd/synthetic.py).
+"""
+import numpy as np
+
+from spriteworld_amd import action_spaces
+from spriteworld_amd import lowering
+from spriteworld_amd import renderers
+from spriteworld_amd import synthetic
+from spriteworld_amd import tasks
+
+
+def _renderers(size, aa):
+  return {'image': renderers.PILRenderer(image_size=(size, size), anti_aliasing=aa,
+                                         color_to_rgb=renderers.hsv_to_rgb)}
+
+
+def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
+  """Returns (SwbConfig, Pool, sample_actions(rng) -> ndarray)."""
+  rng = np.random.default_rng(seed)
+  P = num_envs * episodes_per_env
+  aa = anti_aliasing
+  if name == 'goal_s5':
+    task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
+    aspace = action_spaces.SelectMove(scale=0.25)
+    rend = _renderers(64, aa)
+    hues = [(0.0, 0.4)] * 2 + [(0.5, 0.9)] * 3
+    labels = [[1]] * 2 + [[0]] * 3
+    pool = synthetic.make_pool(rng, P, 5, hues, labels)
+    cfg = lowering.lower_config(task, aspace, rend, True, 20, num_envs, 5, True)
+  elif name == 'cluster_s5':
+    task = tasks.Clustering([None, None], terminate_bonus=0., reward_range=10.)
+    aspace = action_spaces.SelectMove(scale=0.25)
+    rend = _renderers(64, aa)
+    hues = [(0.55, 0.65)] * 2 + [(0.27, 0.37)] * 3
+    labels = [[0]] * 2 + [[1]] * 3
+    pool = synthetic.make_pool(rng, P, 5, hues, labels)
+    cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 5, True)
+  elif name == 'embodied_s12':
+    task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
+    aspace = action_spaces.Embodied(step_size=0.05)
+    rend = _renderers(128, aa)
+    hues = [(0.0, 0.4)] * 4 + [(0.5, 0.9)] * 7
+    labels = [[1]] * 4 + [[0]] * 7
+    pool = synthetic.make_pool(
+        rng, P, 11, hues, labels, shape_names=('square', 'triangle', 'circle', 'star_5', 'spoke_4'),
+        scales=(0.13, 0.2, 0.3), angles=(0, 17, 45, 90), xy_range=(0.2, 0.8),
+        body=dict(scale=0.07, hue=(0.0, 1.0), shape='circle', label=0))
+    cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 12, True)
+  elif name == 'sorting_s4':
+    goals = [(0.75, 0.75), (0.75, 0.25), (0.25, 0.75), (0.25, 0.25)]
+    subs = [tasks.FindGoalPosition(filter_distrib=None, goal_position=g, terminate_distance=0.075,
+                                   raw_reward_multiplier=20.) for g in goals]
+    task = tasks.MetaAggregated(subs, reward_aggregator='sum', termination_criterion='all')
+    aspace = action_spaces.SelectMove(scale=0.25)
+    rend = _renderers(64, aa)
+    hues = [(0.9, 1.0), (0.55, 0.65), (0.27, 0.37), (0.73, 0.83)]
+    labels = [[int(i == j) for j in range(4)] for i in range(4)]
+    pool = synthetic.make_pool(rng, P, 4, hues, labels, n_tasks=4)
+    cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 4, True)
+  else:
+    raise ValueError('unknown workload ' + name)
+  pool.assign_round_robin(num_envs, episodes_per_env)
+
+  if cfg.action_space == 2:
+    def sample(r):
+      return np.stack([r.integers(0, 2, num_envs), r.integers(0, 4, num_envs)], 1).astype(np.int32)
+  else:
+    def sample(r):
+      return r.uniform(0.0, 1.0, size=(num_envs, 4))
+  return cfg, pool, sample
