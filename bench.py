@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the batched Spriteworld step+render hot path on MI355X.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N > 1: launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+  (one process per GPU, RCCL barrier; environments are sharded across ranks with NO data-path
+  collective -- weak scaling, 8192 environments per GPU).
+
+A "step" is one Environment.step() of every environment of the batch, including the 64x64 RGB
+render, with actions and state resident in HBM (reference: spriteworld/environment.py:88-108).
+Workload (BASELINE.json `metric`, configs[2]): 8192 envs x 5 sprites, SelectMove(0.25),
+Clustering reward, 64x64 PILRenderer with anti_aliasing=5 (the COBRA renderer), synthetic pools.
+
+roofline:     algorithmic bytes per launch (12 461 B/env-step) / the fused
+              kernel's mean duration measured with HIP events on the launch stream, vs 8 TB/s HBM.
+cpu_baseline: the CPU oracle (a C port of the reference algorithm, oracle/sw_oracle.c) stepping a
+              bounded sample of the same workload on all host cores of rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+ENVS_PER_GPU = 8192
+WORKLOAD = 'cluster_s5'
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_ACTION_SETS = 16
+
+
+def algorithmic_bytes(cfg):
+  """A = 3*H*W + 28*S + 17 + action_bytes per env-step."""
+  action_bytes = 8 if cfg.action_space == 2 else 16
+  return 3 * cfg.image_h * cfg.image_w + 28 * cfg.max_sprites + 17 + action_bytes
+
+
+def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
+  import torch
+  from spriteworld_amd import engine, workloads
+  cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=4, seed=seed, anti_aliasing=aa)
+  eng = engine.Engine(cfg, pool, device=device)
+  rng = np.random.default_rng(2000 + seed)
+  acts = [torch.as_tensor(sample(rng), device=eng.device) for _ in range(N_ACTION_SETS)]
+  for i in range(warmup):
+    eng.step(acts[i % N_ACTION_SETS])
+  torch.cuda.synchronize(eng.device)
+  eng.timing(True)
+  if barrier:
+    barrier()
+  torch.cuda.synchronize(eng.device)
+  t0 = time.perf_counter()
+  for i in range(steps):
+    eng.step(acts[i % N_ACTION_SETS])
+  torch.cuda.synchronize(eng.device)
+  if barrier:
+    barrier()
+  elapsed = time.perf_counter() - t0
+  kernel_ms, launches = eng.step_time_ms()
+  eng.timing(False)
+  errors = int(eng.error.max().item())
+  a_bytes = algorithmic_bytes(cfg)
+  eng.close()
+  return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, a_bytes=a_bytes, errors=errors)
+
+
+def cpu_baseline(name, aa, budget_s=12.0):
+  """Oracle env-steps/s on all host cores (threads; the C calls release the GIL)."""
+  from concurrent.futures import ThreadPoolExecutor
+  from oracle import oracle
+  from spriteworld_amd import workloads
+  cores = os.cpu_count() or 1
+  n_envs = 64 * cores
+  cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=4, seed=1, anti_aliasing=aa)
+  eng = oracle.Engine(cfg, pool)
+  rng = np.random.default_rng(5)
+  import ctypes as C
+  lib = oracle.lib()
+  obs = np.zeros((n_envs,) + eng.obs_shape, np.uint8)
+  rew = np.zeros(n_envs)
+  bounds = [(i * n_envs // cores, (i + 1) * n_envs // cores) for i in range(cores)]
+
+  def one_step(actions):
+    a = np.ascontiguousarray(actions)
+
+    def work(b):
+      lib.swo_step_range(eng._h, b[0], b[1], a.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p),
+                         rew.ctypes.data_as(C.c_void_p), None, None, None, None)
+    list(pool_exec.map(work, bounds))
+
+  with ThreadPoolExecutor(cores) as pool_exec:
+    one_step(sample(rng))                       # reset step (untimed)
+    one_step(sample(rng))
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s:
+      one_step(sample(rng))
+      steps += 1
+    dt = time.perf_counter() - t0
+  return dict(value=n_envs * steps / dt, unit='env-steps/s', cores=cores, kind='port',
+              sample='%d envs x %d steps of %s (AA=%d) with oracle/sw_oracle.c on %d threads, %.1f s' %
+              (n_envs, steps, name, aa, cores, dt))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=200)
+  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+  ap.add_argument('--workload', default=WORKLOAD)
+  ap.add_argument('--aa', type=int, default=5)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-extra', action='store_true')
+  ap.add_argument('--gather-obs', action='store_true',
+                  help='also all-gather the observation shards over RCCL every step (BASELINE configs[3])')
+  args = ap.parse_args()
+
+  import torch
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus and world > 1:
+    raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+  if args.gpus > 1 and world == 1:
+    raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+  barrier = None
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    barrier = dist.barrier
+  device = local_rank if world > 1 else 0
+
+  res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
+                barrier=barrier, seed=rank)
+  elapsed = res['elapsed']
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  gather = None
+  if args.gather_obs and dist is not None:
+    from spriteworld_amd import distributed as swd
+    gather = swd.bench_allgather(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device, rank)
+
+  if rank != 0:
+    if dist is not None:
+      dist.barrier()
+      dist.destroy_process_group()
+    return
+
+  total_envs = args.envs_per_gpu * args.gpus
+  value = total_envs * args.steps / elapsed
+  kernel_s = res['kernel_ms'] / 1e3 / max(res['launches'], 1)
+  achieved = res['a_bytes'] * args.envs_per_gpu / kernel_s / 1e9
+  out = {
+      'metric': 'env-steps/sec (incl. 64x64 RGB render) at 8192 envs',
+      'value': value,
+      'unit': 'env-steps/s',
+      'n_gpus': args.gpus,
+      'steps': args.steps,
+      'warmup': args.warmup,
+      'ms_per_step': elapsed / args.steps * 1e3,
+      'higher_is_better': True,
+      'scaling': 'weak',
+      'vs_baseline': None,
+      'dtype': 'i32 fixed-point raster/resample + f64 state',
+      'data': 'synthetic',
+      'config': {
+          'workload': 'BASELINE configs[2]: %d envs/GPU x 5 sprites, SelectMove(0.25), Clustering reward, '
+                      '64x64 PILRenderer anti_aliasing=%d, auto-reset from an HBM pool' %
+                      (args.envs_per_gpu, args.aa),
+          'envs_per_gpu': args.envs_per_gpu, 'sprites': 5, 'image': [64, 64], 'anti_aliasing': args.aa,
+          'parallelism': 'env-sharded x%d, no data-path collective' % args.gpus,
+      },
+      'roofline': {
+          'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+          'kernel': 'swb_step_kernel<10,1>', 'kernel_ms': kernel_s * 1e3,
+          'algorithmic_bytes_per_env_step': res['a_bytes'],
+      },
+      'env_errors': res['errors'],
+  }
+  if gather is not None:
+    out['obs_allgather'] = gather
+  if args.gpus == 1 and not args.no_extra:
+    extra = {}
+    short = max(args.steps // 4, 10)
+    for label, (nm, n, aa) in {
+        'cluster_s5_aa1': ('cluster_s5', args.envs_per_gpu, 1),
+        'goal_s5_1024_aa5': ('goal_s5', 1024, 5),
+        'embodied_s12_128_aa5': ('embodied_s12', args.envs_per_gpu, 5),
+    }.items():
+      r = gpu_run(nm, n, short, 5, aa, device)
+      ks = r['kernel_ms'] / 1e3 / max(r['launches'], 1)
+      extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel_ms': ks * 1e3,
+                      'hbm_GBs': r['a_bytes'] * n / ks / 1e9, 'env_errors': r['errors']}
+    out['extra'] = extra
+  if args.gpus == 1 and not args.no_cpu_baseline:
+    out['cpu_baseline'] = cpu_baseline(args.workload, args.aa)
+  print(json.dumps(out))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

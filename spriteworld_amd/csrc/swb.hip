@@ -70,6 +70,7 @@ struct swb_engine {
   double *d_x = nullptr, *d_y = nullptr;
   int32_t *d_nspr = nullptr, *d_entry = nullptr, *d_step_count = nullptr, *d_episode = nullptr;
   uint8_t* d_reset_next = nullptr;
+  uint32_t* d_ovf = nullptr;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -133,7 +134,8 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   p.render_only = render_only;
   if (!render_only && actions == nullptr) return fail(SWB_ERR_INVALID, "actions is NULL");
   const size_t pfx_bytes = ((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15;
-  const size_t per_wave = (v->lds_fixed + (size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15;
+  const size_t per_wave = (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
+                           (size_t)p.max_spans * SWB_WAVE * 4 + 15) & ~(size_t)15;
   p.lds_per_wave = (int32_t)per_wave;
   const size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
@@ -197,6 +199,7 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   p.n_tasks = cfg->n_tasks; p.is_meta = cfg->is_meta; p.meta_aggregator = cfg->meta_aggregator;
   p.meta_termination = cfg->meta_termination; p.meta_terminate_bonus = cfg->meta_terminate_bonus;
   memcpy(p.tasks, cfg->tasks, sizeof(p.tasks));
+  if (const char* dbg = getenv("SWB_DEBUG_PHASE")) p.debug_phase = atoi(dbg);
   if (p.Wc > 1023 || p.Hc > 65535) { delete h; return fail(SWB_ERR_INVALID, "canvas %dx%d too large", p.Wc, p.Hc); }
   if (!pick_variant(p.Wc, p.Wo)) { delete h; return fail(SWB_ERR_INVALID, "canvas width %d / image width %d not supported", p.Wc, p.Wo); }
   const size_t NS = (size_t)p.N * p.S;
@@ -209,6 +212,14 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   rc |= upload(&h->d_episode, (const int32_t*)nullptr, p.N);
   rc |= upload(&h->d_reset_next, (const uint8_t*)nullptr, p.N);
   if (rc) { swb_destroy(h); return SWB_ERR_HIP; }
+  // visible-span lists: M per canvas row in LDS, the (never expected) rest in HBM; a row of Wc
+  // pixels has at most Wc/2 + 1 runs, so M + ovf_cap >= that bound makes overflow impossible.
+  p.max_spans = 12;
+  if (const char* ms = getenv("SWB_MAX_SPANS")) p.max_spans = atoi(ms) < 5 ? 5 : atoi(ms);
+  p.ovf_cap = p.Wc / 2 + 1;
+  rc |= upload(&h->d_ovf, (const uint32_t*)nullptr, (size_t)p.N * 64 * p.ovf_cap);
+  if (rc) { swb_destroy(h); return SWB_ERR_HIP; }
+  p.ovf = h->d_ovf;
   p.x = h->d_x; p.y = h->d_y; p.nspr = h->d_nspr; p.entry = h->d_entry; p.step_count = h->d_step_count;
   p.episode = h->d_episode; p.reset_next = h->d_reset_next;
   *out = h;
@@ -222,7 +233,7 @@ int swb_destroy(swb_handle h) {
   void* bufs[] = {h->d_shape_verts, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
-                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next};
+                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;

@@ -52,13 +52,8 @@ def _run(name, n_envs, steps, aa, seed=0, reward_ulp=0):
   eng.close()
 
 
-# FindGoalPosition rewards go through libm pow(x, 0.5); until the glibc restatement lands in
-# swb_pow.hip.inc the device uses sqrt, which is within 1 ulp of it (see that file).
-FIND_GOAL_REWARD_ULP = 1
-
-
 def test_goal_s5_aa5():
-  _run('goal_s5', 256, 30, 5, reward_ulp=FIND_GOAL_REWARD_ULP * 64)
+  _run('goal_s5', 256, 30, 5)
 
 
 def test_cluster_s5_aa5():
@@ -66,12 +61,12 @@ def test_cluster_s5_aa5():
 
 
 def test_goal_s5_aa1():
-  _run('goal_s5', 256, 12, 1, reward_ulp=FIND_GOAL_REWARD_ULP * 64)
+  _run('goal_s5', 256, 12, 1)
 
 
 def test_embodied_s12_128():
-  _run('embodied_s12', 64, 20, 5, reward_ulp=FIND_GOAL_REWARD_ULP * 64)
+  _run('embodied_s12', 64, 20, 5)
 
 
 def test_sorting_meta():
-  _run('sorting_s4', 128, 20, 5, reward_ulp=FIND_GOAL_REWARD_ULP * 64)
+  _run('sorting_s4', 128, 20, 5)
