@@ -485,13 +485,19 @@ static void task_find_goal(const swb_task* t, int n, const double* x, const doub
 /* scikit-learn 1.7.2 davies_bouldin_score on the assigned sprites, following
  * the float32 (`pos_f32`) or float64 position dtype path.
  * Returns 0 ok, SWB_ENV_ERR_DB_LABELS or SWB_ENV_ERR_DB_ZERO. */
-static int g_fma_dot = 0; /* build-time pinned against sklearn; see swo_set_fma_dot */
-void swo_set_fma_dot(int v) { g_fma_dot = v; }
-
-static double dot2(double a0, double a1, double b0, double b1) {
-  if (g_fma_dot) return fma(a1, b1, a0 * b0);
-  return a0 * b0 + a1 * b1;
-}
+/* float64 dot products of length 2 as the reference's BLAS / einsum calls evaluate them in the
+ * build container (numpy 2.2.6 with its bundled OpenBLAS, FMA kernels; determined empirically,
+ * see tests/test_oracle_vs_third_party.py):
+ *   np.einsum("ij,ij->i", X, X) (sklearn row_norms)          a0*a0 + a1*a1, no FMA
+ *   X @ Y.T with X (n,2), Y (1,2): n == 1 (dot kernel)        fma(a1, b1, a0*b0)
+ *                                  n >= 2 (gemv kernel)       fma(a0, b0, a1*b1)
+ *   X @ X.T (syrk/gemm), x.dot(x) (ddot)                      fma(a1, b1, a0*b0)
+ * For float32 positions (the config-sampled case) every product of two upcast float32 values
+ * is exact in float64, so all of these orders give identical results. */
+void swo_set_fma_dot(int v) { (void)v; }
+static double norm2(double a0, double a1) { return a0 * a0 + a1 * a1; }
+static double dot2_hi(double a0, double a1, double b0, double b1) { return fma(a1, b1, a0 * b0); }
+static double dot2_lo(double a0, double a1, double b0, double b1) { return fma(a0, b0, a1 * b1); }
 
 static int davies_bouldin(int pos_f32, int n, const double* x, const double* y, const int8_t* label,
                           double* score_out) {
@@ -524,11 +530,12 @@ static int davies_bouldin(int pos_f32, int n, const double* x, const double* y, 
        * d = -2*X.Y^T + XX + YY in f64, cast to f32, max(.,0), sqrt in f32 */
       float dist[SWB_MAX_SPRITES];
       int j = 0;
-      const double yy = dot2(m0, m1, m0, m1);
+      const int cnt_total = cnt;
+      const double yy = norm2(m0, m1);
       for (int i = 0; i < m; ++i)
         if (remap[lab[i]] == c) {
-          const double xxn = dot2(px[i], py[i], px[i], py[i]);
-          double d = -2 * dot2(px[i], py[i], m0, m1);
+          const double xxn = norm2(px[i], py[i]);
+          double d = -2 * (cnt_total == 1 ? dot2_hi(px[i], py[i], m0, m1) : dot2_lo(px[i], py[i], m0, m1));
           d += xxn;
           d += yy;
           float df = (float)d;
@@ -551,11 +558,11 @@ static int davies_bouldin(int pos_f32, int n, const double* x, const double* y, 
       c0[c] = m0; c1[c] = m1;
       double dist[SWB_MAX_SPRITES];
       int j = 0;
-      const double yy = dot2(m0, m1, m0, m1);
+      const double yy = norm2(m0, m1);
       for (int i = 0; i < m; ++i)
         if (remap[lab[i]] == c) {
-          const double xxn = dot2(px[i], py[i], px[i], py[i]);
-          double d = -2 * dot2(px[i], py[i], m0, m1);
+          const double xxn = norm2(px[i], py[i]);
+          double d = -2 * (cnt == 1 ? dot2_hi(px[i], py[i], m0, m1) : dot2_lo(px[i], py[i], m0, m1));
           d += xxn;
           d += yy;
           if (!(d > 0.0)) d = 0.0;
@@ -567,11 +574,11 @@ static int davies_bouldin(int pos_f32, int n, const double* x, const double* y, 
   /* centroid_distances = pairwise_distances(centroids) (float64, X is Y) */
   double D[SWB_MAX_SPRITES][SWB_MAX_SPRITES];
   double nn[SWB_MAX_SPRITES];
-  for (int a = 0; a < k; ++a) nn[a] = dot2(c0[a], c1[a], c0[a], c1[a]);
+  for (int a = 0; a < k; ++a) nn[a] = norm2(c0[a], c1[a]);
   int all_d_zero = 1, all_i_zero = 1;
   for (int a = 0; a < k; ++a)
     for (int b = 0; b < k; ++b) {
-      double d = -2 * dot2(c0[a], c1[a], c0[b], c1[b]);
+      double d = -2 * dot2_hi(c0[a], c1[a], c0[b], c1[b]);
       d += nn[a];
       d += nn[b];
       if (!(d > 0.0)) d = 0.0;
@@ -830,7 +837,7 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
         }
       }
       /* np.linalg.norm(motion) = sqrt(dot(m, m)) :104 */
-      cost = -c->motion_cost * sqrt(dot2(m0, m1, m0, m1));
+      cost = -c->motion_cost * sqrt(dot2_hi(m0, m1, m0, m1));   /* x.dot(x): BLAS ddot */
     }
     for (int s = 0; s < n; ++s) {                        /* update_position :98-99 */
       x[s] = move1(c->pos_is_f32, x[s], e->p_xv[en * S + s], c->keep_in_frame);

@@ -1,0 +1,221 @@
+"""Batched Spriteworld environment on MI355X behind the reference's dm_env surface.
+
+`BatchedEnvironment(task, action_space, renderers, init_sprites, keep_in_frame,
+max_episode_length, metadata, num_envs=N)` takes exactly the keyword arguments of
+the reference's `Environment` (reference: spriteworld/environment.py:34-72), i.e.
+the dict a config's `get_config()` returns, plus `num_envs`.  `reset()` /
+`step(actions)` / `observation_spec()` / `action_spec()` / `.action_space` follow
+:74-161 with a leading N axis on every array:
+
+  step_type u8[N] (0 FIRST, 1 MID, 2 LAST), reward f64[N] (NaN where the
+  reference returns None, i.e. on FIRST steps), discount f32[N] (NaN on FIRST),
+  observation {name: tensor}: the PILRenderer's key -> u8[N, H, W, 3] (device
+  tensor), a `Success` renderer's key -> bool[N].
+
+Per-environment auto-reset is the reference's: the step after a LAST step
+ignores its action and returns FIRST (:90-91).  New episodes come from a pool of
+`init_sprites()` draws made on the host (`episodes_per_env` per environment,
+cycled; call `refill_pool()` to draw fresh ones).
+
+`Environment` is the N = 1 form returning `dm_env.TimeStep`s of numpy values, a
+drop-in for the reference class in `example_run_loop.py:62-80`.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from spriteworld_amd import _abi
+from spriteworld_amd import dm_env_compat as dm_env
+from spriteworld_amd import engine as _engine
+from spriteworld_amd import lowering
+
+BatchedTimeStep = collections.namedtuple('BatchedTimeStep',
+                                         ['step_type', 'reward', 'discount', 'observation'])
+
+
+class EnvironmentError_(RuntimeError):
+  pass
+
+
+class BatchedEnvironment(object):
+  """N independent Spriteworld environments stepped by one fused HIP kernel."""
+
+  def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
+               max_episode_length=1000, metadata=None, num_envs=1, episodes_per_env=8,
+               max_sprites=None, device=0, check_errors=True):
+    self._task = task
+    self._action_space = action_space
+    self._renderers = renderers
+    self._init_sprites = init_sprites
+    self._keep_in_frame = keep_in_frame
+    self._max_episode_length = max_episode_length
+    self._metadata = metadata
+    self._num_envs = int(num_envs)
+    self._episodes_per_env = int(episodes_per_env)
+    self._check_errors = check_errors
+    self._image_key, self._pil = lowering.find_pil_renderer(renderers)
+    self._success_keys = [k for k, r in renderers.items() if type(r).__name__ == 'Success']
+    unsupported = [k for k, r in renderers.items()
+                   if k != self._image_key and k not in self._success_keys]
+    if unsupported:
+      raise lowering.LoweringError('renderers not supported on device: %s' % unsupported)
+    episodes = self._draw_episodes()
+    S = max_sprites or max([len(ep) for ep in episodes] + [1])
+    self._max_sprites = S
+    pos_dt = lowering.position_dtype(episodes)
+    self._cfg = lowering.lower_config(task, action_space, renderers, keep_in_frame,
+                                      max_episode_length, self._num_envs, S,
+                                      pos_is_f32=(pos_dt == np.float32))
+    pool = lowering.lower_episodes(episodes, task, renderers, max_sprites=S)
+    pool.assign_round_robin(self._num_envs, self._episodes_per_env)
+    self._engine = _engine.Engine(self._cfg, pool, device=device)
+    self._render = self._pil is not None
+
+  # ------------------------------------------------------------------ pool
+  def _draw_episodes(self):
+    return [list(self._init_sprites()) for _ in range(self._num_envs * self._episodes_per_env)]
+
+  def refill_pool(self):
+    """Draws a fresh pool with init_sprites(); every environment restarts (next step is FIRST)."""
+    episodes = self._draw_episodes()
+    pool = lowering.lower_episodes(episodes, self._task, self._renderers,
+                                   max_sprites=self._max_sprites)
+    pool.assign_round_robin(self._num_envs, self._episodes_per_env)
+    self._engine.set_pool(pool)
+
+  # ------------------------------------------------------------------ dm_env surface
+  @property
+  def num_envs(self):
+    return self._num_envs
+
+  @property
+  def action_space(self):
+    return self._action_space
+
+  @property
+  def engine(self):
+    return self._engine
+
+  def action_spec(self):
+    return self._action_space.action_spec()
+
+  def observation_spec(self):
+    spec = {}
+    if self._image_key is not None:
+      spec[self._image_key] = self._pil.observation_spec()
+    for k in self._success_keys:
+      spec[k] = dm_env.specs.Array(shape=(), dtype=np.bool_)
+    return spec
+
+  def _timestep(self):
+    e = self._engine
+    if self._check_errors:
+      err = int(e.error.max().item())
+      if err:
+        if err & _abi.ENV_ERR_DB_ZERO:
+          raise ZeroDivisionError('float division by zero (Davies-Bouldin score is 0)')
+        if err & _abi.ENV_ERR_DB_LABELS:
+          raise ValueError('Number of labels is invalid for davies_bouldin_score')
+        raise EnvironmentError_('internal engine error bits 0x%x' % err)
+    obs = {}
+    if self._image_key is not None:
+      obs[self._image_key] = e.obs
+    for k in self._success_keys:
+      obs[k] = e.success.bool()
+    return BatchedTimeStep(e.step_type, e.reward, e.discount, obs)
+
+  def reset(self):
+    """Environment.reset() for every environment: returns the FIRST time steps."""
+    self._engine.reset_all()
+    return self.step(self.null_actions())
+
+  def null_actions(self):
+    if self._cfg.action_space == _abi.ACTION_EMBODIED:
+      return torch.zeros((self._num_envs, 2), dtype=torch.int32, device=self._engine.device)
+    return torch.zeros((self._num_envs, 4), dtype=torch.float64, device=self._engine.device)
+
+  def step(self, actions):
+    """actions: [N, 4] float (SelectMove / DragAndDrop) or [N, 2] int (Embodied)."""
+    self._engine.step(actions, render=self._render)
+    return self._timestep()
+
+  def observation(self):
+    obs = {}
+    if self._image_key is not None:
+      obs[self._image_key] = self._engine.render()
+    for k in self._success_keys:
+      obs[k] = self._engine.success.bool()
+    return obs
+
+  def state(self):
+    """Live structure-of-arrays state (host copies): x, y [N, S], n_sprites, step_count, ..."""
+    return self._engine.state()
+
+  def sample_actions(self):
+    return self._action_space.sample(self._num_envs)
+
+  def close(self):
+    self._engine.close()
+
+
+class Environment(object):
+  """Single environment with the reference's exact return types (dm_env.TimeStep of numpy)."""
+
+  def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
+               max_episode_length=1000, metadata=None, episodes_per_pool=32, device=0):
+    self._batched = BatchedEnvironment(
+        task, action_space, renderers, init_sprites, keep_in_frame=keep_in_frame,
+        max_episode_length=max_episode_length, metadata=metadata, num_envs=1,
+        episodes_per_env=episodes_per_pool, device=device)
+    self._episodes_per_pool = episodes_per_pool
+    self._episodes_used = 0
+    self._reset_next_step = True
+
+  @property
+  def action_space(self):
+    return self._batched.action_space
+
+  def action_spec(self):
+    return self._batched.action_spec()
+
+  def observation_spec(self):
+    return self._batched.observation_spec()
+
+  def _convert(self, ts):
+    step_type = dm_env.StepType(int(ts.step_type[0].item()))
+    obs = {}
+    for k, v in ts.observation.items():
+      a = v[0].cpu().numpy()
+      obs[k] = bool(a) if a.shape == () else a
+    if step_type == dm_env.StepType.FIRST:
+      return dm_env.TimeStep(step_type, None, None, obs)
+    return dm_env.TimeStep(step_type, float(ts.reward[0].item()), float(ts.discount[0].item()), obs)
+
+  def _maybe_refill(self):
+    # a fresh draw of init_sprites() per episode, like the reference; the pool is re-drawn when used up
+    if self._episodes_used >= self._episodes_per_pool:
+      self._batched.refill_pool()
+      self._episodes_used = 0
+    self._episodes_used += 1
+
+  def reset(self):
+    self._maybe_refill()
+    ts = self._convert(self._batched.reset())
+    self._reset_next_step = False
+    return ts
+
+  def step(self, action):
+    if self._reset_next_step:
+      return self.reset()
+    a = np.asarray(action)[None]
+    ts = self._convert(self._batched.step(a))
+    if ts.last():
+      self._reset_next_step = True
+    return ts
+
+  def state(self):
+    return self._batched.state()
+
+  def close(self):
+    self._batched.close()

@@ -76,6 +76,32 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     labels = [[int(i == j) for j in range(4)] for i in range(4)]
     pool = synthetic.make_pool(rng, P, 4, hues, labels, n_tasks=4)
     cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 4, True)
+  elif name in ('f64_drag', 'f64_cluster'):
+    # test-style sprites: float64 positions, rotations, non-convex shapes, velocities, no clipping
+    rend = {'image': renderers.PILRenderer(image_size=(32, 32), anti_aliasing=aa if aa != 5 else 3,
+                                           bg_color=(10, 200, 30))}
+    if name == 'f64_drag':
+      task = tasks.FindGoalPosition(goal_position=(0.3, 0.6), terminate_distance=0.1,
+                                    terminate_bonus=5., weights_dimensions=(1, 3),
+                                    raw_reward_multiplier=7)
+      aspace = action_spaces.DragAndDrop(scale=0.5, motion_cost=1.3)
+      labels = [[1], [1], [0], [1]]
+    else:
+      task = tasks.Clustering([None, None, None], termination_threshold=1.5, terminate_bonus=2.,
+                              reward_range=4.)
+      aspace = action_spaces.SelectMove(scale=0.3, motion_cost=0.7)
+      labels = [[0], [1], [2], [0], [1], [-1]]
+    ns = len(labels)
+    pool = synthetic.make_pool(
+        rng, P, ns, [(0.0, 1.0)] * ns, labels,
+        shape_names=('star_5', 'spoke_4', 'hexagon', 'triangle', 'star_6', 'spoke_6', 'octagon'),
+        scales=(0.1, 0.2, 0.35), angles=tuple(range(0, 360, 7)), xy_range=(0.1, 0.9))
+    # float64 positions with full mantissas and small velocities
+    pool.x[:] = rng.uniform(0.1, 0.9, size=pool.x.shape)
+    pool.y[:] = rng.uniform(0.1, 0.9, size=pool.y.shape)
+    pool.x_vel[:] = rng.uniform(-0.02, 0.02, size=pool.x.shape)
+    pool.y_vel[:] = rng.uniform(-0.02, 0.02, size=pool.x.shape)
+    cfg = lowering.lower_config(task, aspace, rend, False, 15, num_envs, ns, False)
   else:
     raise ValueError('unknown workload ' + name)
   pool.assign_round_robin(num_envs, episodes_per_env)

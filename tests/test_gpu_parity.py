@@ -70,3 +70,15 @@ def test_embodied_s12_128():
 
 def test_sorting_meta():
   _run('sorting_s4', 128, 20, 5)
+
+
+def test_f64_sprites_drag_and_drop_motion_cost():
+  _run('f64_drag', 256, 40, 3)
+
+
+def test_f64_sprites_clustering_three_clusters():
+  _run('f64_cluster', 256, 40, 3)
+
+
+def test_cluster_s5_aa1():
+  _run('cluster_s5', 128, 10, 1)

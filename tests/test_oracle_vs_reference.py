@@ -1,0 +1,113 @@
+"""Pins the oracle against the UNMODIFIED reference imported from /root/reference (build
+container only; skipped where the reference tree is absent, e.g. on the GPU box)."""
+import copy
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import ref_harness
+
+pytestmark = pytest.mark.skipif(not ref_harness.reference_available(),
+                                reason='reference tree not present')
+
+CONFIGS = [
+    ('spriteworld.configs.cobra.goal_finding_new_position', 'train'),
+    ('spriteworld.configs.cobra.goal_finding_new_shape', 'test'),
+    ('spriteworld.configs.cobra.goal_finding_more_distractors', 'test'),
+    ('spriteworld.configs.cobra.goal_finding_more_targets', 'train'),
+    ('spriteworld.configs.cobra.clustering', 'test'),
+    ('spriteworld.configs.cobra.sorting', 'test'),
+    ('spriteworld.configs.cobra.exploration', 'train'),
+    ('spriteworld.configs.examples.goal_finding_embodied', 'test'),
+    ('spriteworld.configs.examples.goal_finding_clustering', 'test'),
+]
+
+
+def _bits(v):
+  return np.float64(v).view(np.uint64)
+
+
+@pytest.mark.parametrize('module,mode', CONFIGS)
+def test_oracle_equals_reference_environment(module, mode, capsys):
+  ref_harness.load_reference()
+  from spriteworld import environment
+  from spriteworld import renderers as ref_renderers
+  from oracle import oracle
+  from spriteworld_amd import lowering
+  seed, n_eps, n_steps = 21, 30, 250
+  with capsys.disabled():
+    pass
+  np.random.seed(seed)
+  config = importlib.import_module(module).get_config(mode)
+  episodes = [config['init_sprites']() for _ in range(n_eps)]
+  task, aspace, rends = config['task'], config['action_space'], config['renderers']
+  S = max(len(e) for e in episodes)
+  cfg = lowering.lower_config(task, aspace, rends, True, config['max_episode_length'], 1, S,
+                              pos_is_f32=(lowering.position_dtype(episodes) == np.float32))
+  pool = lowering.lower_episodes(episodes, task, rends, max_sprites=S).assign_round_robin(1)
+  eng = oracle.Engine(cfg, pool)
+  it = iter([copy.deepcopy(episodes[0])] + [copy.deepcopy(e) for e in episodes] * 20)
+  config = dict(config, init_sprites=lambda: next(it))
+  config['renderers'] = dict(rends, success=ref_renderers.Success())
+  env = environment.Environment(**config)
+  rng = np.random.RandomState(seed + 1)
+  for t in range(n_steps):
+    if cfg.action_space == 2:
+      a = np.array([rng.randint(0, 2), rng.randint(0, 4)])
+      ts = env.step([int(a[0]), int(a[1])])
+    else:
+      a = rng.uniform(0, 1, 4)
+      ts = env.step(a)
+    out = eng.step(a[None])
+    assert int(ts.step_type) == int(out['step_type'][0]), t
+    r = np.nan if ts.reward is None else float(ts.reward)
+    assert (np.isnan(r) and np.isnan(out['reward'][0])) or _bits(r) == _bits(out['reward'][0]), (t, r)
+    assert bool(ts.observation['success']) == bool(out['success'][0]), t
+    assert np.array_equal(ts.observation['image'], out['obs'][0]), t
+    st = eng.state()
+    pos = np.array([s.position for s in env._sprites], dtype=np.float64).reshape(-1, 2)
+    n = st['n_sprites'][0]
+    assert n == len(pos)
+    assert np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
+
+
+def test_float64_sprites_and_motion_cost():
+  """Test-style sprites built from Python floats (float64 positions) and a non-zero motion cost."""
+  ref_harness.load_reference()
+  from spriteworld import action_spaces, environment, renderers, sprite, tasks
+  from oracle import oracle
+  from spriteworld_amd import lowering
+  rng = np.random.RandomState(5)
+
+  def gen():
+    return [sprite.Sprite(x=float(rng.uniform(0.1, 0.9)), y=float(rng.uniform(0.1, 0.9)),
+                          shape=str(rng.choice(['star_5', 'spoke_4', 'hexagon', 'triangle'])),
+                          angle=int(rng.randint(0, 360)), scale=float(rng.choice([0.1, 0.2, 0.35])),
+                          c0=int(rng.randint(0, 256)), c1=int(rng.randint(0, 256)), c2=int(rng.randint(0, 256)),
+                          x_vel=float(rng.uniform(-0.02, 0.02)), y_vel=float(rng.uniform(-0.02, 0.02)))
+            for _ in range(4)]
+
+  episodes = [gen() for _ in range(12)]
+  for aspace in (action_spaces.SelectMove(scale=0.3, motion_cost=0.7),
+                 action_spaces.DragAndDrop(scale=0.5, motion_cost=1.3)):
+    task = tasks.FindGoalPosition(goal_position=(0.3, 0.6), terminate_distance=0.1, terminate_bonus=5.,
+                                  weights_dimensions=(1, 3), raw_reward_multiplier=7)
+    rends = {'image': renderers.PILRenderer(image_size=(32, 32), anti_aliasing=3, bg_color=(10, 200, 30))}
+    cfg = lowering.lower_config(task, aspace, rends, False, 15, 1, 4,
+                                pos_is_f32=(lowering.position_dtype(episodes) == np.float32))
+    assert cfg.pos_is_f32 == 0
+    pool = lowering.lower_episodes(episodes, task, rends, max_sprites=4).assign_round_robin(1)
+    eng = oracle.Engine(cfg, pool)
+    it = iter([copy.deepcopy(episodes[0])] + [copy.deepcopy(e) for e in episodes] * 20)
+    env = environment.Environment(task=task, action_space=aspace, renderers=rends,
+                                  init_sprites=lambda: next(it), keep_in_frame=False, max_episode_length=15)
+    arng = np.random.RandomState(9)
+    for t in range(150):
+      a = arng.uniform(0, 1, 4)
+      ts = env.step(a)
+      out = eng.step(a[None])
+      assert int(ts.step_type) == int(out['step_type'][0]), t
+      r = np.nan if ts.reward is None else float(ts.reward)
+      assert (np.isnan(r) and np.isnan(out['reward'][0])) or _bits(r) == _bits(out['reward'][0]), (t, r, out['reward'][0])
+      assert np.array_equal(ts.observation['image'], out['obs'][0]), t
