@@ -314,6 +314,30 @@ int swo_lanczos_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk) 
   return ksize;
 }
 
+/* Per-thread scratch (canvas, intermediate, coefficient tables) so that the multi-threaded
+ * cpu_baseline of bench.py measures arithmetic, not malloc/mmap contention. */
+typedef struct { void* p; size_t cap; } scratch_t;
+static __thread scratch_t tl_canvas, tl_small, tl_tmp;
+static void* scratch(scratch_t* s, size_t bytes) {
+  if (s->cap < bytes) { free(s->p); s->p = malloc(bytes); s->cap = bytes; }
+  return s->p;
+}
+typedef struct { int in, out, ks; int32_t* b; int32_t* k; } coeff_cache_t;
+static __thread coeff_cache_t tl_coeff[4];
+static const coeff_cache_t* cached_coeffs(int in, int out) {
+  for (int i = 0; i < 4; ++i)
+    if (tl_coeff[i].b && tl_coeff[i].in == in && tl_coeff[i].out == out) return &tl_coeff[i];
+  static __thread int next = 0;
+  coeff_cache_t* c = &tl_coeff[next];
+  next = (next + 1) & 3;
+  free(c->b); free(c->k);
+  c->in = in; c->out = out; c->ks = swo_lanczos_ksize(in, out);
+  c->b = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)out);
+  c->k = (int32_t*)malloc(sizeof(int32_t) * (size_t)out * c->ks);
+  swo_lanczos_coeffs(in, out, c->b, c->k);
+  return c;
+}
+
 static uint8_t clip8(int in) {
   const int v = in >> PRECISION_BITS; /* arithmetic shift, as Pillow's lookup index */
   return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
@@ -322,14 +346,13 @@ static uint8_t clip8(int in) {
 /* Resample.c ImagingResample: horizontal pass then vertical pass, uint8
  * intermediate, 3 bands.  src [Hc][Wc][3] -> dst [H][W][3]. */
 static void resample_lanczos(const uint8_t* src, int Wc, int Hc, uint8_t* dst, int W, int H) {
-  const int ksh = swo_lanczos_ksize(Wc, W), ksv = swo_lanczos_ksize(Hc, H);
-  int32_t* bh = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)W);
-  int32_t* kh = (int32_t*)malloc(sizeof(int32_t) * (size_t)W * ksh);
-  int32_t* bv = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)H);
-  int32_t* kv = (int32_t*)malloc(sizeof(int32_t) * (size_t)H * ksv);
-  swo_lanczos_coeffs(Wc, W, bh, kh);
-  swo_lanczos_coeffs(Hc, H, bv, kv);
-  uint8_t* tmp = (uint8_t*)malloc((size_t)Hc * W * 3);
+  const coeff_cache_t* ch = cached_coeffs(Wc, W);
+  const int ksh = ch->ks;
+  const int32_t *bh = ch->b, *kh = ch->k;
+  const coeff_cache_t* cv = cached_coeffs(Hc, H);   /* may evict ch only if > 4 size pairs are live */
+  const int ksv = cv->ks;
+  const int32_t *bv = cv->b, *kv = cv->k;
+  uint8_t* tmp = (uint8_t*)scratch(&tl_tmp, (size_t)Hc * W * 3);
   for (int yy = 0; yy < Hc; ++yy)
     for (int xx = 0; xx < W; ++xx) {
       const int xmin = bh[2 * xx], xmax = bh[2 * xx + 1];
@@ -355,7 +378,6 @@ static void resample_lanczos(const uint8_t* src, int Wc, int Hc, uint8_t* dst, i
       o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
     }
   }
-  free(tmp); free(bh); free(kh); free(bv); free(kv);
 }
 
 /* Raw entry for differential tests against PIL.Image.resize(LANCZOS). */
@@ -380,7 +402,7 @@ static void render_env(const swb_config* cfg, int n, const double* x, const doub
   const int AA = cfg->anti_aliasing;
   const int Wo = cfg->image_h, Ho = cfg->image_w;     /* PIL (width, height) of the output */
   const int Wc = AA * Wo, Hc = AA * Ho;
-  uint8_t* canvas = (uint8_t*)malloc((size_t)Wc * Hc * 3);
+  uint8_t* canvas = (uint8_t*)scratch(&tl_canvas, (size_t)Wc * Hc * 3);
   for (size_t i = 0; i < (size_t)Wc * Hc; ++i) {      /* canvas.paste(bg) :79 */
     canvas[3 * i] = cfg->bg_rgb[0]; canvas[3 * i + 1] = cfg->bg_rgb[1]; canvas[3 * i + 2] = cfg->bg_rgb[2];
   }
@@ -399,14 +421,12 @@ static void render_env(const swb_config* cfg, int n, const double* x, const doub
   uint8_t* img = canvas;
   uint8_t* small = NULL;
   if (AA != 1) {                                        /* resize(..., ANTIALIAS) :84; same size => copy */
-    small = (uint8_t*)malloc((size_t)Wo * Ho * 3);
+    small = (uint8_t*)scratch(&tl_small, (size_t)Wo * Ho * 3);
     resample_lanczos(canvas, Wc, Hc, small, Wo, Ho);
     img = small;
   }
   for (int r = 0; r < Ho; ++r)                          /* np.flipud :90 */
     memcpy(obs + (size_t)r * Wo * 3, img + (size_t)(Ho - 1 - r) * Wo * 3, (size_t)Wo * 3);
-  free(canvas);
-  free(small);
 }
 
 /* ------------------------------------------------------------------------- */
