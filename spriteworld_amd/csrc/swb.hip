@@ -134,8 +134,11 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   p.render_only = render_only;
   if (!render_only && actions == nullptr) return fail(SWB_ERR_INVALID, "actions is NULL");
   const size_t pfx_bytes = ((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15;
+  // centred paths (16 B per vertex): inside the mask arrays when they are large enough
+  const size_t cpath_bytes = (size_t)p.max_edges * 16;
+  p.cpath_in_masks = (2 * (size_t)v->nw * SWB_WAVE * 4 >= cpath_bytes) ? 1 : 0;
   const size_t per_wave = (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
-                           (size_t)p.max_spans * SWB_WAVE * 4 + 15) & ~(size_t)15;
+                           (size_t)p.max_spans * SWB_WAVE * 4 + (p.cpath_in_masks ? 0 : cpath_bytes) + 15) & ~(size_t)15;
   p.lds_per_wave = (int32_t)per_wave;
   const size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
@@ -215,7 +218,7 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   // visible-span lists: M per canvas row in LDS, the (never expected) rest in HBM; a row of Wc
   // pixels has at most Wc/2 + 1 runs, so M + ovf_cap >= that bound makes overflow impossible.
   p.max_spans = 12;
-  if (const char* ms = getenv("SWB_MAX_SPANS")) p.max_spans = atoi(ms) < 5 ? 5 : atoi(ms);
+  if (const char* ms = getenv("SWB_MAX_SPANS")) p.max_spans = atoi(ms) < 6 ? 6 : atoi(ms);
   p.ovf_cap = p.Wc / 2 + 1;
   rc |= upload(&h->d_ovf, (const uint32_t*)nullptr, (size_t)p.N * 64 * p.ovf_cap);
   if (rc) { swb_destroy(h); return SWB_ERR_HIP; }
