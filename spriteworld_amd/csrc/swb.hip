@@ -53,7 +53,7 @@ struct swb_engine {
   int device = 0;
   swb_params p;        // device pointers + config, passed by value to the kernel
   bool have_shapes = false, have_h = false, have_v = false, have_pool = false;
-  int nw = 0, ncol = 0;
+  int nw = 0, ncol = 0, vslots = SWB_VSLOTS;
   size_t lds_block = 0;
   // owned device buffers
   double* d_shape_verts = nullptr;
@@ -82,22 +82,24 @@ namespace {
 
 typedef void (*kernel_fn)(const swb_params);
 
-struct variant { int nw, ncol; kernel_fn fn; size_t lds_fixed; };
+struct variant { int nw, ncol, vs; kernel_fn fn; size_t lds_fixed; };
 
-template <int NW, int NCOL>
+template <int NW, int NCOL, int VS>
 variant make_variant() {
-  return {NW, NCOL, swb_step_kernel<NW, NCOL>, (sizeof(wave_lds<NW>) + 15) & ~(size_t)15};
+  return {NW, NCOL, VS, swb_step_kernel<NW, NCOL, VS>, (sizeof(wave_lds<NW>) + 15) & ~(size_t)15};
 }
 
-// canvas widths up to 32*NW pixels, image widths up to 64*NCOL pixels
+// canvas widths up to 32*NW pixels, image widths up to 64*NCOL pixels, up to VS output rows in
+// flight in the vertical pass (first match wins)
 const variant kVariants[] = {
-    make_variant<2, 1>(),  make_variant<4, 1>(),  make_variant<4, 2>(),  make_variant<5, 1>(),
-    make_variant<10, 1>(), make_variant<10, 2>(), make_variant<20, 2>(), make_variant<20, 4>(),
+    make_variant<2, 1, 8>(),  make_variant<4, 1, 8>(),  make_variant<4, 2, 8>(),  make_variant<5, 1, 8>(),
+    make_variant<10, 1, 6>(), make_variant<10, 1, 8>(), make_variant<10, 2, 8>(),
+    make_variant<20, 2, 6>(), make_variant<20, 2, 8>(), make_variant<20, 4, 8>(),
 };
 
-const variant* pick_variant(int Wc, int Wo) {
+const variant* pick_variant(int Wc, int Wo, int vslots = SWB_VSLOTS) {
   for (const variant& v : kVariants)
-    if (32 * v.nw >= Wc && 64 * v.ncol >= Wo) return &v;
+    if (32 * v.nw >= Wc && 64 * v.ncol >= Wo && v.vs >= vslots) return &v;
   return nullptr;
 }
 
@@ -121,7 +123,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   const swb_config& c = h->cfg;
   if (c.anti_aliasing != 1 && !(h->have_h && h->have_v))
     return fail(SWB_ERR_STATE, "swb_upload_resample (both axes) is required when anti_aliasing > 1");
-  const variant* v = pick_variant(h->p.Wc, h->p.Wo);
+  const variant* v = pick_variant(h->p.Wc, h->p.Wo, h->vslots);
   if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d / image width %d not supported", h->p.Wc, h->p.Hc, h->p.Wo);
   swb_params p = h->p;
   p.actions = actions;
@@ -300,6 +302,7 @@ int swb_upload_resample(swb_handle h, int32_t axis, int32_t out_size, int32_t ks
       vend[r] = ymin + c - 1;
       if (r > 0 && (vend[r] < vend[r - 1] || ymin < bounds[2 * (r - 1)])) return fail(SWB_ERR_INVALID, "vertical windows are not monotone");
     }
+    int used = 1;
     for (int y = 0; y < p.Hc; ++y) {
       int rf = 0;
       while (rf < out_size && vend[rf] < y) ++rf;     // rows completed before canvas row y
@@ -309,10 +312,12 @@ int swb_upload_resample(swb_handle h, int32_t axis, int32_t out_size, int32_t ks
         const int k = r - rf;
         if (k < 0 || k >= SWB_VSLOTS) return fail(SWB_ERR_INVALID, "more than %d output rows in flight at canvas row %d", SWB_VSLOTS, y);
         vtab[(size_t)y * SWB_VSLOTS + k] = coeffs[(size_t)r * ksize + (y - ymin)];
+        if (k + 1 > used) used = k + 1;
       }
     }
     if (upload(&h->d_v_tab, vtab.data(), vtab.size()) || upload(&h->d_v_end, vend.data(), vend.size())) return SWB_ERR_HIP;
     h->p.v_tab = h->d_v_tab; h->p.v_end = h->d_v_end;
+    h->vslots = used;
     h->have_v = true;
   } else {
     return fail(SWB_ERR_INVALID, "axis must be 0 or 1");
