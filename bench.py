@@ -41,6 +41,18 @@ def algorithmic_bytes(cfg):
   return 3 * cfg.image_h * cfg.image_w + 28 * cfg.max_sprites + 17 + action_bytes
 
 
+def measured_traffic(args):
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None.
+
+  bench.py cannot collect PMC counters itself; the figure is the one measured for this round's
+  kernel on the default workload (see profiles/r01_traffic.json for the passes and corrections)."""
+  path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+  if args.workload != WORKLOAD or args.envs_per_gpu != ENVS_PER_GPU or args.aa != 5 or not os.path.exists(path):
+    return None
+  with open(path) as f:
+    return json.load(f)['traffic_bytes_per_launch']
+
+
 def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
   import torch
   from spriteworld_amd import engine, workloads
@@ -185,7 +197,7 @@ def main():
       },
       'roofline': {
           'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-          'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+          'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(args),
           'kernel': 'swb_step_kernel<10,1>', 'kernel_ms': kernel_s * 1e3,
           'algorithmic_bytes_per_env_step': res['a_bytes'],
       },
