@@ -82,12 +82,28 @@ def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
   return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, a_bytes=a_bytes, errors=errors)
 
 
+def usable_cores():
+  """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+  try:
+    cores = len(os.sched_getaffinity(0))
+  except AttributeError:
+    cores = os.cpu_count() or 1
+  try:
+    with open('/sys/fs/cgroup/cpu.max') as f:
+      quota, period = f.read().split()
+    if quota != 'max':
+      cores = max(1, min(cores, int(int(quota) / int(period))))
+  except (OSError, ValueError):
+    pass
+  return cores
+
+
 def cpu_baseline(name, aa, budget_s=12.0):
   """Oracle env-steps/s on all host cores (threads; the C calls release the GIL)."""
   from concurrent.futures import ThreadPoolExecutor
   from oracle import oracle
   from spriteworld_amd import workloads
-  cores = os.cpu_count() or 1
+  cores = usable_cores()
   n_envs = 64 * cores
   cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=4, seed=1, anti_aliasing=aa)
   eng = oracle.Engine(cfg, pool)
@@ -198,7 +214,7 @@ def main():
       'roofline': {
           'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
           'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(args),
-          'kernel': 'swb_step_kernel<10,1>', 'kernel_ms': kernel_s * 1e3,
+          'kernel': 'swb_step_kernel<10,1,6>', 'kernel_ms': kernel_s * 1e3,
           'algorithmic_bytes_per_env_step': res['a_bytes'],
       },
       'env_errors': res['errors'],

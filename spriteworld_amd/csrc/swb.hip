@@ -219,7 +219,7 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   if (rc) { swb_destroy(h); return SWB_ERR_HIP; }
   // visible-span lists: M per canvas row in LDS, the (never expected) rest in HBM; a row of Wc
   // pixels has at most Wc/2 + 1 runs, so M + ovf_cap >= that bound makes overflow impossible.
-  p.max_spans = 12;
+  p.max_spans = 6;
   if (const char* ms = getenv("SWB_MAX_SPANS")) p.max_spans = atoi(ms) < 6 ? 6 : atoi(ms);
   p.ovf_cap = p.Wc / 2 + 1;
   rc |= upload(&h->d_ovf, (const uint32_t*)nullptr, (size_t)p.N * 64 * p.ovf_cap);
