@@ -138,7 +138,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   const size_t pfx_bytes = ((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15;
   // centred paths (16 B per vertex): inside the mask arrays when they are large enough
   const size_t cpath_bytes = (size_t)p.max_edges * 16;
-  p.cpath_in_masks = (2 * (size_t)v->nw * SWB_WAVE * 4 >= cpath_bytes) ? 1 : 0;
+  p.cpath_in_masks = (2 * (size_t)SWB_NWA(v->nw) * SWB_WAVE * 4 >= cpath_bytes) ? 1 : 0;
   const size_t per_wave = (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
                            (size_t)p.max_spans * SWB_WAVE * 4 + (p.cpath_in_masks ? 0 : cpath_bytes) + 15) & ~(size_t)15;
   p.lds_per_wave = (int32_t)per_wave;

@@ -76,6 +76,16 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     labels = [[int(i == j) for j in range(4)] for i in range(4)]
     pool = synthetic.make_pool(rng, P, 4, hues, labels, n_tasks=4)
     cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 4, True)
+  elif name == 'wide_s4':
+    # very large, rotated, partly off-canvas sprites: exercises x-chunked scan conversion, clipping
+    task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
+    aspace = action_spaces.SelectMove(scale=0.5)
+    rend = _renderers(64, aa)
+    pool = synthetic.make_pool(
+        rng, P, 4, [(0.0, 1.0)] * 4, [[1]] * 4,
+        shape_names=('square', 'triangle', 'circle', 'star_4', 'spoke_5', 'pentagon'),
+        scales=(0.5, 0.7, 0.95, 1.3), angles=tuple(range(0, 360, 11)), xy_range=(0.0, 1.0))
+    cfg = lowering.lower_config(task, aspace, rend, True, 20, num_envs, 4, True)
   elif name in ('f64_drag', 'f64_cluster'):
     # test-style sprites: float64 positions, rotations, non-convex shapes, velocities, no clipping
     rend = {'image': renderers.PILRenderer(image_size=(32, 32), anti_aliasing=aa if aa != 5 else 3,

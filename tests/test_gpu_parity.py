@@ -82,3 +82,11 @@ def test_f64_sprites_clustering_three_clusters():
 
 def test_cluster_s5_aa1():
   _run('cluster_s5', 128, 10, 1)
+
+
+def test_wide_sprites_chunked_scan_conversion():
+  _run('wide_s4', 128, 12, 5)
+
+
+def test_wide_sprites_aa1():
+  _run('wide_s4', 128, 8, 1)
