@@ -76,6 +76,17 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     labels = [[int(i == j) for j in range(4)] for i in range(4)]
     pool = synthetic.make_pool(rng, P, 4, hues, labels, n_tasks=4)
     cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 4, True)
+  elif name == 'tiny_s6':
+    # sprites of a few canvas pixels: vertices collapse onto shared integer points (degenerate
+    # edges, duplicate vertices), which takes the general branch of the corner rule
+    task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
+    aspace = action_spaces.SelectMove(scale=0.5)
+    rend = _renderers(64, aa)
+    pool = synthetic.make_pool(
+        rng, P, 6, [(0.0, 1.0)] * 6, [[1]] * 6,
+        shape_names=('circle', 'star_6', 'spoke_6', 'octagon', 'spoke_5', 'star_5'),
+        scales=(0.004, 0.01, 0.02, 0.035, 0.05), angles=tuple(range(0, 360, 13)), xy_range=(0.0, 1.0))
+    cfg = lowering.lower_config(task, aspace, rend, True, 20, num_envs, 6, True)
   elif name == 'wide_s4':
     # very large, rotated, partly off-canvas sprites: exercises x-chunked scan conversion, clipping
     task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)

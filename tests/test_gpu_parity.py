@@ -90,3 +90,11 @@ def test_wide_sprites_chunked_scan_conversion():
 
 def test_wide_sprites_aa1():
   _run('wide_s4', 128, 8, 1)
+
+
+def test_tiny_sprites_degenerate_polygons():
+  _run('tiny_s6', 256, 10, 5)
+
+
+def test_tiny_sprites_aa1():
+  _run('tiny_s6', 256, 6, 1)
