@@ -51,8 +51,8 @@ enum swb_status {
 
 /* action_spaces.py: which class the `actions` buffer is interpreted as. */
 enum swb_action_space {
-  SWB_ACTION_SELECT_MOVE = 0,   /* f64[N,4]  action_spaces.py:29-111  */
-  SWB_ACTION_DRAG_AND_DROP = 1, /* f64[N,4]  action_spaces.py:114-137 */
+  SWB_ACTION_SELECT_MOVE = 0,   /* f64[N,4] (or f32, see action_is_f32)  action_spaces.py:29-111  */
+  SWB_ACTION_DRAG_AND_DROP = 1, /* f64[N,4] (or f32)                     action_spaces.py:114-137 */
   SWB_ACTION_EMBODIED = 2       /* i32[N,2]  action_spaces.py:140-221 */
 };
 
@@ -109,6 +109,9 @@ typedef struct swb_config {
   int32_t is_meta;            /* task is tasks.MetaAggregated                         */
   int32_t meta_aggregator;    /* swb_meta_aggregator                                  */
   int32_t meta_termination;   /* swb_meta_termination                                 */
+  int32_t action_is_f32;      /* 1: actions are float32[N,4] (the dtype action_spec()  */
+                              /* declares, action_spaces.py:62-63): motion, click point*/
+                              /* and cost then follow numpy's float32 arithmetic       */
   double meta_terminate_bonus;/* MetaAggregated _terminate_bonus                      */
   swb_task tasks[SWB_MAX_TASKS];
 } swb_config;
@@ -186,8 +189,8 @@ int swb_set_pool(swb_handle h, const swb_pool* pool);
 /* Environment.reset() for all envs: the next swb_step is a FIRST step. */
 int swb_reset_all(swb_handle h, void* stream);
 
-/* Environment.step(): actions_dev is f64[N,4] (SelectMove/DragAndDrop) or
- * i32[N,2] (Embodied). */
+/* Environment.step(): actions_dev is f64[N,4] (f32[N,4] when cfg.action_is_f32) for
+ * SelectMove/DragAndDrop, or i32[N,2] for Embodied. */
 int swb_step(swb_handle h, const void* actions_dev, const swb_outputs* out, void* stream);
 
 /* observation() only (no state change): obs_dev u8[N,H,W,3]. */

@@ -158,7 +158,8 @@ class Engine(object):
     if cfg.action_space == _abi.ACTION_EMBODIED:
       actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.N, 2)
     else:
-      actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.N, 4)
+      adt = np.float32 if cfg.action_is_f32 else np.float64
+      actions = np.ascontiguousarray(actions, dtype=adt).reshape(self.N, 4)
     i0, i1 = (0, self.N) if env_range is None else env_range
     out = {
         'obs': np.zeros((self.N,) + self.obs_shape, dtype=np.uint8) if render else None,

@@ -812,6 +812,8 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
     const double *scale = e->p_scale + en * S, *ca = e->p_ca + en * S, *sa = e->p_sa + en * S;
     e->step_count[i] += 1;                               /* :93 */
     double cost = 0.0;
+    float cost_f32 = 0.0f;
+    int cost_is_f32 = 0;
     double cx[SWB_MAX_SHAPE_VERTS], cy[SWB_MAX_SHAPE_VERTS];
     if (c->action_space == SWB_ACTION_EMBODIED) {        /* action_spaces.py:187-214 */
       const int32_t* a = (const int32_t*)actions + 2 * i;
@@ -839,6 +841,31 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
         y[body] = move1(c->pos_is_f32, y[body], m1, c->keep_in_frame);
       }
       cost = -c->motion_cost * st;                       /* :214 */
+    } else if (c->action_is_f32) {                       /* action_spaces.py:83-104, float32 actions */
+      /* numpy (NEP 50) keeps float32: (a - 0.5) * scale and the click point minus a float32
+       * position are float32 operations; a float64 position promotes them to float64. */
+      const float* a = (const float*)actions + 4 * i;
+      const float sc = (float)c->action_scale;
+      float m0f, m1f;
+      if (c->action_space == SWB_ACTION_DRAG_AND_DROP) { m0f = (a[2] - a[0]) * sc; m1f = (a[3] - a[1]) * sc; }
+      else { m0f = (a[2] - 0.5f) * sc; m1f = (a[3] - 0.5f) * sc; }
+      for (int s = n - 1; s >= 0; --s) {
+        double tx, ty;
+        if (c->pos_is_f32) { tx = (double)(a[0] - (float)x[s]); ty = (double)(a[1] - (float)y[s]); }
+        else { tx = (double)a[0] - x[s]; ty = (double)a[1] - y[s]; }
+        const int nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+        if (point_in_centered_path(nv, cx, cy, tx, ty)) {
+          x[s] = move1(c->pos_is_f32, x[s], (double)m0f, c->keep_in_frame);
+          y[s] = move1(c->pos_is_f32, y[s], (double)m1f, c->keep_in_frame);
+          break;
+        }
+      }
+      /* np.linalg.norm of a float32 vector: float32 products and sum (no FMA), float32 sqrt;
+       * -motion_cost (Python float, weak) * np.float32 -> np.float32 */
+      const float sq = m0f * m0f + m1f * m1f;
+      cost_f32 = (float)(-c->motion_cost) * sqrtf(sq);
+      cost = (double)cost_f32;
+      cost_is_f32 = 1;
     } else {                                             /* action_spaces.py:83-104 */
       const double* a = (const double*)actions + 4 * i;
       double m0, m1;
@@ -867,7 +894,13 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
     observe(e, i, obs, &ok, &err, &tr);                  /* :101-102 */
     if (success) success[i] = ok;
     if (error) error[i] = err;
-    if (reward) reward[i] = cost + tr;                   /* reward += task.reward */
+    if (reward) {                                        /* reward += task.reward */
+      /* np.float32 cost + Python-float task reward stays float32 under NEP 50 (NoReward and
+       * Clustering return Python floats; FindGoalPosition / MetaAggregated return np.float64) */
+      const int task_is_pyfloat = !c->is_meta && c->tasks[0].kind != SWB_TASK_FIND_GOAL;
+      if (cost_is_f32 && task_is_pyfloat) reward[i] = (double)(cost_f32 + (float)tr);
+      else reward[i] = cost + tr;
+    }
     int oof = 0;                                         /* sprite.py:135-138 */
     for (int s = 0; s < n; ++s)
       if (!(x[s] >= 0. && y[s] >= 0. && x[s] <= 1. && y[s] <= 1.)) oof = 1;

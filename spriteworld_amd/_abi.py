@@ -51,6 +51,7 @@ class SwbConfig(C.Structure):
       ('is_meta', C.c_int32),
       ('meta_aggregator', C.c_int32),
       ('meta_termination', C.c_int32),
+      ('action_is_f32', C.c_int32),
       ('meta_terminate_bonus', C.c_double),
       ('tasks', SwbTask * SWB_MAX_TASKS),
   ]

@@ -200,6 +200,7 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   p.bg = (uint32_t)cfg->bg_rgb[0] | ((uint32_t)cfg->bg_rgb[1] << 8) | ((uint32_t)cfg->bg_rgb[2] << 16);
   p.action_space = cfg->action_space; p.keep_in_frame = cfg->keep_in_frame;
   p.max_episode_length = cfg->max_episode_length; p.pos_is_f32 = cfg->pos_is_f32;
+  p.action_is_f32 = cfg->action_is_f32;
   p.action_scale = cfg->action_scale; p.motion_cost = cfg->motion_cost;
   p.n_tasks = cfg->n_tasks; p.is_meta = cfg->is_meta; p.meta_aggregator = cfg->meta_aggregator;
   p.meta_termination = cfg->meta_termination; p.meta_terminate_bonus = cfg->meta_terminate_bonus;

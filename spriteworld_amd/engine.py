@@ -88,8 +88,11 @@ class Engine(object):
     _lib.check(self.lib.swb_reset_all(self._h, self._stream()))
 
   def step(self, actions, render=True):
-    """actions: device tensor f64[N,4] (SelectMove/DragAndDrop) or i32[N,2] (Embodied)."""
-    want = torch.int32 if self.cfg.action_space == _abi.ACTION_EMBODIED else torch.float64
+    """actions: device tensor f64[N,4] (f32 if cfg.action_is_f32) or i32[N,2] (Embodied)."""
+    if self.cfg.action_space == _abi.ACTION_EMBODIED:
+      want = torch.int32
+    else:
+      want = torch.float32 if self.cfg.action_is_f32 else torch.float64
     if not isinstance(actions, torch.Tensor):
       actions = torch.as_tensor(np.ascontiguousarray(actions), device=self.device)
     if actions.dtype != want or actions.device != self.device or not actions.is_contiguous():

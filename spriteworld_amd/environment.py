@@ -43,7 +43,7 @@ class BatchedEnvironment(object):
 
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, num_envs=1, episodes_per_env=8,
-               max_sprites=None, device=0, check_errors=True):
+               max_sprites=None, device=0, check_errors=True, action_dtype=np.float64):
     self._task = task
     self._action_space = action_space
     self._renderers = renderers
@@ -66,7 +66,8 @@ class BatchedEnvironment(object):
     pos_dt = lowering.position_dtype(episodes)
     self._cfg = lowering.lower_config(task, action_space, renderers, keep_in_frame,
                                       max_episode_length, self._num_envs, S,
-                                      pos_is_f32=(pos_dt == np.float32))
+                                      pos_is_f32=(pos_dt == np.float32), action_dtype=action_dtype)
+    self._noise_scale = None
     pool = lowering.lower_episodes(episodes, task, renderers, max_sprites=S)
     pool.assign_round_robin(self._num_envs, self._episodes_per_env)
     self._engine = _engine.Engine(self._cfg, pool, device=device)
@@ -133,7 +134,8 @@ class BatchedEnvironment(object):
   def null_actions(self):
     if self._cfg.action_space == _abi.ACTION_EMBODIED:
       return torch.zeros((self._num_envs, 2), dtype=torch.int32, device=self._engine.device)
-    return torch.zeros((self._num_envs, 4), dtype=torch.float64, device=self._engine.device)
+    dt = torch.float32 if self._cfg.action_is_f32 else torch.float64
+    return torch.zeros((self._num_envs, 4), dtype=dt, device=self._engine.device)
 
   def step(self, actions):
     """actions: [N, 4] float (SelectMove / DragAndDrop) or [N, 2] int (Embodied)."""
@@ -163,11 +165,12 @@ class Environment(object):
   """Single environment with the reference's exact return types (dm_env.TimeStep of numpy)."""
 
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
-               max_episode_length=1000, metadata=None, episodes_per_pool=32, device=0):
+               max_episode_length=1000, metadata=None, episodes_per_pool=32, device=0,
+               action_dtype=np.float64):
     self._batched = BatchedEnvironment(
         task, action_space, renderers, init_sprites, keep_in_frame=keep_in_frame,
         max_episode_length=max_episode_length, metadata=metadata, num_envs=1,
-        episodes_per_env=episodes_per_pool, device=device)
+        episodes_per_env=episodes_per_pool, device=device, action_dtype=action_dtype)
     self._episodes_per_pool = episodes_per_pool
     self._episodes_used = 0
     self._reset_next_step = True

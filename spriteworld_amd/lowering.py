@@ -88,8 +88,13 @@ def _bg_of(renderer):
 
 
 def lower_config(task, action_space, renderers, keep_in_frame=True, max_episode_length=1000,
-                 num_envs=1, max_sprites=1, pos_is_f32=True):
-  """Builds the SwbConfig for Environment(task, action_space, renderers, ...)."""
+                 num_envs=1, max_sprites=1, pos_is_f32=True, action_dtype=np.float64):
+  """Builds the SwbConfig for Environment(task, action_space, renderers, ...).
+
+  `action_dtype`: np.float64 (what the reference's `action_space.sample()` returns) or
+  np.float32 (what its `action_spec()` declares); numpy's promotion rules make the two
+  differ in the last bits of motions, click offsets and some rewards, so the engine follows
+  whichever the caller uses.  Ignored for Embodied (integer actions)."""
   cfg = _abi.SwbConfig()
   cfg.n_envs = int(num_envs)
   cfg.max_sprites = int(max_sprites)
@@ -119,6 +124,10 @@ def lower_config(task, action_space, renderers, keep_in_frame=True, max_episode_
     cfg.motion_cost = float(action_space._motion_cost)
   else:
     raise LoweringError('unsupported action space: ' + name)
+  if np.dtype(action_dtype) not in (np.dtype(np.float32), np.dtype(np.float64)):
+    raise LoweringError('action_dtype must be float32 or float64')
+  cfg.action_is_f32 = int(np.dtype(action_dtype) == np.dtype(np.float32) and
+                          cfg.action_space != _abi.ACTION_EMBODIED)
   cfg.keep_in_frame = int(bool(keep_in_frame))
   cfg.max_episode_length = int(max_episode_length)
   cfg.pos_is_f32 = int(bool(pos_is_f32))

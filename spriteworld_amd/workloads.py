@@ -34,7 +34,12 @@ def _renderers(size, aa):
 
 
 def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
-  """Returns (SwbConfig, Pool, sample_actions(rng) -> ndarray)."""
+  """Returns (SwbConfig, Pool, sample_actions(rng) -> ndarray).
+
+  A name ending in `_f32a` is the same workload driven with float32 actions."""
+  f32_actions = name.endswith('_f32a')
+  if f32_actions:
+    name = name[:-len('_f32a')]
   rng = np.random.default_rng(seed)
   P = num_envs * episodes_per_env
   aa = anti_aliasing
@@ -126,11 +131,14 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
   else:
     raise ValueError('unknown workload ' + name)
   pool.assign_round_robin(num_envs, episodes_per_env)
+  if f32_actions and cfg.action_space != 2:
+    cfg.action_is_f32 = 1
 
   if cfg.action_space == 2:
     def sample(r):
       return np.stack([r.integers(0, 2, num_envs), r.integers(0, 4, num_envs)], 1).astype(np.int32)
   else:
     def sample(r):
-      return r.uniform(0.0, 1.0, size=(num_envs, 4))
+      a = r.uniform(0.0, 1.0, size=(num_envs, 4))
+      return a.astype(np.float32) if cfg.action_is_f32 else a
   return cfg, pool, sample

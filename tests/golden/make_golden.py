@@ -39,6 +39,9 @@ CASES = [
     ('cobra_exploration', 'spriteworld.configs.cobra.exploration', 'train', 24, 200, 15),
     ('examples_embodied', 'spriteworld.configs.examples.goal_finding_embodied', 'train', 8, 200, 16),
     ('examples_goal_clustering', 'spriteworld.configs.examples.goal_finding_clustering', 'train', 8, 160, 17),
+    # float32 action arrays (the dtype action_spec() declares), with a motion cost
+    ('cobra_clustering_f32_actions', 'spriteworld.configs.cobra.clustering', 'test', 12, 200, 18, 'float32', 0.6),
+    ('cobra_sorting_f32_actions', 'spriteworld.configs.cobra.sorting', 'test', 12, 160, 19, 'float32', 0.25),
 ]
 FULL_FRAMES = 6
 
@@ -52,19 +55,21 @@ def versions():
       ' '.join(platform.libc_ver()), platform.python_version())
 
 
-def make(name, module, mode, n_eps, n_steps, seed):
-  from spriteworld import environment
+def make(name, module, mode, n_eps, n_steps, seed, action_dtype='float64', motion_cost=None):
+  from spriteworld import action_spaces, environment
   from spriteworld import renderers as ref_renderers
   mod = importlib.import_module(module)
   np.random.seed(seed)
   config = mod.get_config(mode)
+  if motion_cost is not None:
+    config['action_space'] = action_spaces.SelectMove(scale=0.25, motion_cost=motion_cost)
   gen = config['init_sprites']
   episodes = [gen() for _ in range(n_eps)]
   task, aspace, rends = config['task'], config['action_space'], config['renderers']
   S = max(len(e) for e in episodes)
   pos_dt = lowering.position_dtype(episodes)
   cfg = lowering.lower_config(task, aspace, rends, True, config['max_episode_length'], 1, S,
-                              pos_is_f32=(pos_dt == np.float32))
+                              pos_is_f32=(pos_dt == np.float32), action_dtype=np.dtype(action_dtype))
   pool = lowering.lower_episodes(episodes, task, rends, max_sprites=S).assign_round_robin(1)
   # reference run, replaying the same episodes (the constructor draws once, environment.py:68)
   it = iter([copy.deepcopy(episodes[0])] + [copy.deepcopy(e) for e in episodes] * 50)
@@ -75,7 +80,7 @@ def make(name, module, mode, n_eps, n_steps, seed):
   env = environment.Environment(**config)
   rng = np.random.RandomState(seed + 1000)
   embodied = cfg.action_space == 2
-  actions = np.zeros((n_steps, 2), np.int32) if embodied else np.zeros((n_steps, 4), np.float64)
+  actions = np.zeros((n_steps, 2), np.int32) if embodied else np.zeros((n_steps, 4), np.dtype(action_dtype))
   out = dict(step_type=np.zeros(n_steps, np.uint8), reward=np.zeros(n_steps, np.float64),
              discount=np.zeros(n_steps, np.float32), success=np.zeros(n_steps, np.uint8),
              x=np.zeros((n_steps, S)), y=np.zeros((n_steps, S)), n_sprites=np.zeros(n_steps, np.int32),
@@ -86,7 +91,7 @@ def make(name, module, mode, n_eps, n_steps, seed):
       a = np.array([rng.randint(0, 2), rng.randint(0, 4)])
       ts = env.step([int(a[0]), int(a[1])])
     else:
-      a = rng.uniform(0, 1, 4)
+      a = rng.uniform(0, 1, 4).astype(action_dtype)
       ts = env.step(a)
     actions[t] = a
     out['step_type'][t] = int(ts.step_type)

@@ -98,3 +98,10 @@ def test_tiny_sprites_degenerate_polygons():
 
 def test_tiny_sprites_aa1():
   _run('tiny_s6', 256, 6, 1)
+
+
+@pytest.mark.parametrize('name,aa', [('goal_s5_f32a', 5), ('cluster_s5_f32a', 5), ('f64_drag_f32a', 3),
+                                     ('f64_cluster_f32a', 3), ('sorting_s4_f32a', 5)])
+def test_float32_actions(name, aa):
+  """Actions of the dtype action_spec() declares: float32 motion / click / cost arithmetic (NEP 50)."""
+  _run(name, 192, 25, aa)

@@ -111,3 +111,49 @@ def test_float64_sprites_and_motion_cost():
       r = np.nan if ts.reward is None else float(ts.reward)
       assert (np.isnan(r) and np.isnan(out['reward'][0])) or _bits(r) == _bits(out['reward'][0]), (t, r, out['reward'][0])
       assert np.array_equal(ts.observation['image'], out['obs'][0]), t
+
+
+@pytest.mark.parametrize('module,mode,motion_cost', [
+    ('spriteworld.configs.cobra.goal_finding_more_distractors', 'train', 0.0),
+    ('spriteworld.configs.cobra.clustering', 'train', 0.0),
+    ('spriteworld.configs.cobra.clustering', 'test', 0.6),
+    ('spriteworld.configs.cobra.sorting', 'train', 0.3),
+    ('spriteworld.configs.cobra.exploration', 'train', 1.1),
+])
+def test_float32_actions_match_reference(module, mode, motion_cost):
+  """float32 action arrays (the dtype action_spec() declares): numpy keeps float32 arithmetic."""
+  ref_harness.load_reference()
+  from spriteworld import action_spaces, environment
+  from spriteworld import renderers as ref_renderers
+  from oracle import oracle
+  from spriteworld_amd import lowering
+  seed, n_eps, n_steps = 33, 20, 200
+  np.random.seed(seed)
+  config = importlib.import_module(module).get_config(mode)
+  config['action_space'] = action_spaces.SelectMove(scale=0.25, motion_cost=motion_cost)
+  episodes = [config['init_sprites']() for _ in range(n_eps)]
+  task, aspace, rends = config['task'], config['action_space'], config['renderers']
+  S = max(len(e) for e in episodes)
+  cfg = lowering.lower_config(task, aspace, rends, True, config['max_episode_length'], 1, S,
+                              pos_is_f32=(lowering.position_dtype(episodes) == np.float32),
+                              action_dtype=np.float32)
+  assert cfg.action_is_f32 == 1
+  pool = lowering.lower_episodes(episodes, task, rends, max_sprites=S).assign_round_robin(1)
+  eng = oracle.Engine(cfg, pool)
+  it = iter([copy.deepcopy(episodes[0])] + [copy.deepcopy(e) for e in episodes] * 20)
+  config = dict(config, init_sprites=lambda: next(it))
+  config['renderers'] = dict(rends, success=ref_renderers.Success())
+  env = environment.Environment(**config)
+  rng = np.random.RandomState(seed + 1)
+  for t in range(n_steps):
+    a = rng.uniform(0, 1, 4).astype(np.float32)
+    ts = env.step(a)
+    out = eng.step(a[None])
+    assert int(ts.step_type) == int(out['step_type'][0]), t
+    r = np.nan if ts.reward is None else float(ts.reward)
+    assert (np.isnan(r) and np.isnan(out['reward'][0])) or _bits(r) == _bits(out['reward'][0]), (t, r, out['reward'][0])
+    assert np.array_equal(ts.observation['image'], out['obs'][0]), t
+    pos = np.array([s.position for s in env._sprites], dtype=np.float64).reshape(-1, 2)
+    st = eng.state()
+    n = st['n_sprites'][0]
+    assert np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
