@@ -141,6 +141,8 @@ typedef struct swb_pool {
   const int8_t* label;        /* [P,n_tasks,S]                                        */
   const int32_t* pool_base;   /* [N]                                                  */
   const int32_t* pool_len;    /* [N]                                                  */
+  const double* angle;        /* [P,S]   degrees; only for swb_factors (may be NULL)  */
+  const double* color;        /* [P,S,3] c0,c1,c2; only for swb_factors (may be NULL) */
 } swb_pool;
 
 /* Per-step outputs, device memory, caller-owned.  Any pointer may be NULL. */
@@ -195,6 +197,11 @@ int swb_step(swb_handle h, const void* actions_dev, const swb_outputs* out, void
 
 /* observation() only (no state change): obs_dev u8[N,H,W,3]. */
 int swb_render(swb_handle h, uint8_t* obs_dev, void* stream);
+
+/* SpriteFactors observation (renderers/handcrafted.py:29-82): factors_dev f64[N,S,10] in
+ * sprite.FACTOR_NAMES order (x, y, shape, angle, scale, c0, c1, c2, x_vel, y_vel), `shape` as its
+ * constants.ShapeType value (1-based); rows >= n_sprites[env] are zero. */
+int swb_factors(swb_handle h, double* factors_dev, void* stream);
 
 /* Blocking state access (synchronises `stream`). */
 int swb_get_state(swb_handle h, const swb_state* host_state, void* stream);

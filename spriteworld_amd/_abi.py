@@ -73,6 +73,8 @@ class SwbPool(C.Structure):
       ('label', C.c_void_p),
       ('pool_base', C.c_void_p),
       ('pool_len', C.c_void_p),
+      ('angle', C.c_void_p),
+      ('color', C.c_void_p),
   ]
 
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libswb.so')
 # Every symbol include/swb.h declares (tests check the library exports them all).
 EXPORTS = (
     'swb_last_error', 'swb_version', 'swb_create', 'swb_destroy', 'swb_upload_shapes',
-    'swb_upload_resample', 'swb_set_pool', 'swb_reset_all', 'swb_step', 'swb_render',
+    'swb_upload_resample', 'swb_set_pool', 'swb_reset_all', 'swb_step', 'swb_render', 'swb_factors',
     'swb_get_state', 'swb_set_positions', 'swb_timing_enable', 'swb_step_time_ms',
 )
 
@@ -50,6 +50,7 @@ def load():
   lib.swb_reset_all.argtypes = [C.c_void_p, C.c_void_p]
   lib.swb_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.SwbOutputs), C.c_void_p]
   lib.swb_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+  lib.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   lib.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
   lib.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   lib.swb_timing_enable.argtypes = [C.c_void_p, C.c_int32]

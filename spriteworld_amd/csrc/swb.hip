@@ -67,6 +67,7 @@ struct swb_engine {
   uint32_t* d_p_rgb = nullptr;
   int8_t* d_p_label = nullptr;
   int32_t *d_pool_base = nullptr, *d_pool_len = nullptr;
+  double *d_p_angle = nullptr, *d_p_color = nullptr;
   double *d_x = nullptr, *d_y = nullptr;
   int32_t *d_nspr = nullptr, *d_entry = nullptr, *d_step_count = nullptr, *d_episode = nullptr;
   uint8_t* d_reset_next = nullptr;
@@ -239,7 +240,7 @@ int swb_destroy(swb_handle h) {
   void* bufs[] = {h->d_shape_verts, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
-                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf};
+                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_p_angle, h->d_p_color};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;
@@ -352,7 +353,11 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
   rc |= upload(&h->d_p_label, pool->label, (size_t)P * T * S);
   rc |= upload(&h->d_pool_base, pool->pool_base, N);
   rc |= upload(&h->d_pool_len, pool->pool_len, N);
+  if (pool->angle) rc |= upload(&h->d_p_angle, pool->angle, PS);
+  if (pool->color) rc |= upload(&h->d_p_color, pool->color, PS * 3);
   if (rc) return SWB_ERR_HIP;
+  h->p.p_angle = pool->angle ? h->d_p_angle : nullptr;
+  h->p.p_color = pool->color ? h->d_p_color : nullptr;
   swb_params& p = h->p;
   p.p_n = h->d_p_n; p.p_x = h->d_p_x; p.p_y = h->d_p_y; p.p_xv = h->d_p_xv; p.p_yv = h->d_p_yv;
   p.p_scale = h->d_p_scale; p.p_ca = h->d_p_ca; p.p_sa = h->d_p_sa; p.p_shape = h->d_p_shape; p.p_rgb = h->d_p_rgb;
@@ -384,6 +389,16 @@ int swb_render(swb_handle h, uint8_t* obs_dev, void* stream) {
   memset(&out, 0, sizeof(out));
   out.obs = obs_dev;
   return launch(h, nullptr, &out, 1, (hipStream_t)stream);
+}
+
+int swb_factors(swb_handle h, double* factors_dev, void* stream) {
+  if (!h || !factors_dev) return fail(SWB_ERR_INVALID, "null argument");
+  if (!h->have_pool) return fail(SWB_ERR_STATE, "swb_set_pool has not been called");
+  HIP_TRY(hipSetDevice(h->device));
+  const int total = h->p.N * h->p.S;
+  hipLaunchKernelGGL(swb_factors_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->p, factors_dev);
+  HIP_TRY(hipGetLastError());
+  return SWB_OK;
 }
 
 int swb_get_state(swb_handle h, const swb_state* st, void* stream) {

@@ -107,6 +107,13 @@ class Engine(object):
     _lib.check(self.lib.swb_render(self._h, C.c_void_p(self.obs.data_ptr()), self._stream()))
     return self.obs
 
+  def factors(self):
+    """SpriteFactors observation: f64 [N, S, 10] device tensor (FACTOR_NAMES order, shape as ShapeType id)."""
+    if getattr(self, '_factors', None) is None:
+      self._factors = torch.zeros((self.N, self.S, 10), dtype=torch.float64, device=self.device)
+    _lib.check(self.lib.swb_factors(self._h, C.c_void_p(self._factors.data_ptr()), self._stream()))
+    return self._factors
+
   def state(self):
     st = {
         'x': np.zeros((self.N, self.S)), 'y': np.zeros((self.N, self.S)),

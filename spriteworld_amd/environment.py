@@ -56,8 +56,9 @@ class BatchedEnvironment(object):
     self._check_errors = check_errors
     self._image_key, self._pil = lowering.find_pil_renderer(renderers)
     self._success_keys = [k for k, r in renderers.items() if type(r).__name__ == 'Success']
+    self._factor_keys = {k: r for k, r in renderers.items() if type(r).__name__ == 'SpriteFactors'}
     unsupported = [k for k, r in renderers.items()
-                   if k != self._image_key and k not in self._success_keys]
+                   if k != self._image_key and k not in self._success_keys and k not in self._factor_keys]
     if unsupported:
       raise lowering.LoweringError('renderers not supported on device: %s' % unsupported)
     episodes = self._draw_episodes()
@@ -67,7 +68,10 @@ class BatchedEnvironment(object):
     self._cfg = lowering.lower_config(task, action_space, renderers, keep_in_frame,
                                       max_episode_length, self._num_envs, S,
                                       pos_is_f32=(pos_dt == np.float32), action_dtype=action_dtype)
-    self._noise_scale = None
+    # SelectMove noise (action_spaces.py:69-75) is added to the action tensor on the device
+    ns = getattr(action_space, '_noise_scale', None)
+    self._noise_scale = None if not ns else torch.as_tensor(np.asarray(ns, dtype=np.float64))
+    self._noise_gen = None
     pool = lowering.lower_episodes(episodes, task, renderers, max_sprites=S)
     pool.assign_round_robin(self._num_envs, self._episodes_per_env)
     self._engine = _engine.Engine(self._cfg, pool, device=device)
@@ -107,6 +111,8 @@ class BatchedEnvironment(object):
       spec[self._image_key] = self._pil.observation_spec()
     for k in self._success_keys:
       spec[k] = dm_env.specs.Array(shape=(), dtype=np.bool_)
+    for k, r in self._factor_keys.items():
+      spec[k] = dm_env.specs.Array(shape=(self._max_sprites, len(r._factors)), dtype=np.float64)
     return spec
 
   def _timestep(self):
@@ -124,7 +130,22 @@ class BatchedEnvironment(object):
       obs[self._image_key] = e.obs
     for k in self._success_keys:
       obs[k] = e.success.bool()
+    self._add_factor_obs(obs)
     return BatchedTimeStep(e.step_type, e.reward, e.discount, obs)
+
+  def _add_factor_obs(self, obs):
+    if not self._factor_keys:
+      return
+    from spriteworld_amd import sprite as sprite_lib
+    full = self._engine.factors()
+    for k, r in self._factor_keys.items():
+      cols = [sprite_lib.FACTOR_NAMES.index(f) for f in r._factors]
+      obs[k] = full if cols == list(range(10)) else full[:, :, cols]
+
+  def seed_noise(self, seed):
+    """Seeds the generator of the SelectMove action noise."""
+    self._noise_gen = torch.Generator(device=self._engine.device)
+    self._noise_gen.manual_seed(int(seed))
 
   def reset(self):
     """Environment.reset() for every environment: returns the FIRST time steps."""
@@ -139,6 +160,13 @@ class BatchedEnvironment(object):
 
   def step(self, actions):
     """actions: [N, 4] float (SelectMove / DragAndDrop) or [N, 2] int (Embodied)."""
+    if self._noise_scale is not None:
+      e = self._engine
+      if not isinstance(actions, torch.Tensor):
+        actions = torch.as_tensor(np.ascontiguousarray(actions))
+      actions = actions.to(device=e.device, dtype=torch.float32 if self._cfg.action_is_f32 else torch.float64)
+      noise = torch.randn(actions.shape, dtype=torch.float64, device=e.device, generator=self._noise_gen)
+      actions = (actions.to(torch.float64) + noise * self._noise_scale.to(e.device)).to(actions.dtype)
     self._engine.step(actions, render=self._render)
     return self._timestep()
 
@@ -148,6 +176,7 @@ class BatchedEnvironment(object):
       obs[self._image_key] = self._engine.render()
     for k in self._success_keys:
       obs[k] = self._engine.success.bool()
+    self._add_factor_obs(obs)
     return obs
 
   def state(self):

@@ -115,9 +115,8 @@ def lower_config(task, action_space, renderers, keep_in_frame=True, max_episode_
                         _abi.ACTION_DRAG_AND_DROP)
     cfg.action_scale = float(action_space._scale)
     cfg.motion_cost = float(action_space._motion_cost)
-    if getattr(action_space, '_noise_scale', None):
-      raise LoweringError('SelectMove noise_scale is applied by the caller: pass pre-noised '
-                          'actions (see DESIGN.md, out-of-scope list)')
+    # _noise_scale is not lowered: the noise is added to the action tensor by the caller
+    # (BatchedEnvironment.step does it on the device), as the reference adds it before anything else
   elif name == 'Embodied':
     cfg.action_space = _abi.ACTION_EMBODIED
     cfg.action_scale = float(action_space._step_size)
@@ -196,6 +195,9 @@ class Pool(object):
     s.n_entries = self.n_entries
     for name in self.FIELDS:
       setattr(s, name, getattr(self, name).ctypes.data)
+    self.angle = np.ascontiguousarray(self.angle, dtype=np.float64)
+    self.color = np.ascontiguousarray(self.color, dtype=np.float64)
+    s.angle, s.color = self.angle.ctypes.data, self.color.ctypes.data
     return s
 
 

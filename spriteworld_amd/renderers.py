@@ -49,3 +49,22 @@ class Success(object):
 
   def observation_spec(self):
     return specs.Array(shape=(), dtype=np.bool_)
+
+
+class SpriteFactors(object):
+  """Observation of the sprites' factors (mirror of the reference renderer's constructor).
+
+  Batched form: a float64 device tensor [N, S, len(factors)] in the order of `factors`, `shape`
+  as its ShapeType value; rows of sprite slots beyond an environment's sprite count are zero
+  (the reference returns a list of per-sprite dicts of Python floats)."""
+
+  def __init__(self, factors=None):
+    from spriteworld_amd import sprite as sprite_lib
+    factors = sprite_lib.FACTOR_NAMES if factors is None else tuple(factors)
+    if not set(factors).issubset(set(sprite_lib.FACTOR_NAMES)):
+      raise ValueError('Factors have to belong to {}.'.format(sprite_lib.FACTOR_NAMES))
+    self._factors = factors
+    self._per_object_spec = {f: specs.Array(shape=(), dtype=np.float32) for f in factors}
+
+  def observation_spec(self):
+    return self._per_object_spec

@@ -76,8 +76,6 @@ def test_lower_config_and_episodes():
 def test_lowering_rejects_what_the_engine_cannot_do():
   config = _cobra_like_config()
   with pytest.raises(lowering.LoweringError):
-    lowering.lower_config(config['task'], action_spaces.SelectMove(noise_scale=0.1), config['renderers'])
-  with pytest.raises(lowering.LoweringError):
     lowering.lower_config(config['task'], config['action_space'], config['renderers'], max_sprites=99)
   with pytest.raises(lowering.LoweringError):
     lowering.position_dtype([[Sprite(x=0.1, y=0.2), Sprite(x=np.float32(0.1), y=np.float32(0.2))]])
@@ -144,4 +142,35 @@ def test_single_environment_follows_example_run_loop():
     assert n <= 20 and timestep.discount == 0.0
     assert isinstance(timestep.observation['success'], bool)
     assert timestep.observation['image'].shape == (64, 64, 3) and np.isfinite(np.nanmean(rewards))
+  env.close()
+
+
+@pytest.mark.gpu
+def test_sprite_factors_observation_and_action_noise():
+  """handcrafted.SpriteFactors as a batched tensor, and SelectMove(noise_scale=...) noise."""
+  import torch
+  from spriteworld_amd import environment, shapes
+  np.random.seed(4)
+  config = _cobra_like_config()
+  config['renderers'] = {'factors': renderers.SpriteFactors(), 'xy': renderers.SpriteFactors(factors=('y', 'x', 'shape'))}
+  config['action_space'] = action_spaces.SelectMove(scale=0.25, noise_scale=0.05)
+  env = environment.BatchedEnvironment(num_envs=32, episodes_per_env=2, **config)
+  env.seed_noise(0)
+  ts = env.reset()
+  f = ts.observation['factors'].cpu().numpy()
+  assert f.shape == (32, 3, 10) and ts.observation['xy'].shape == (32, 3, 3)
+  pool, st = env.engine.pool, env.state()
+  for n in range(32):
+    e = st['pool_entry'][n]
+    assert np.array_equal(f[n, :, 0], st['x'][n]) and np.array_equal(f[n, :, 1], st['y'][n])
+    assert np.array_equal(f[n, :, 2], pool.shape[e] + 1) and np.array_equal(f[n, :, 4], pool.scale[e])
+    assert np.array_equal(f[n, :, 5:8], pool.color[e]) and np.array_equal(f[n, :, 3], pool.angle[e])
+  assert np.array_equal(ts.observation['xy'].cpu().numpy(), f[:, :, [1, 0, 2]])
+  # noise: the same clean action moves sprites by different amounts in different environments
+  a = np.tile(np.array([[0.5, 0.5, 0.9, 0.9]]), (32, 1))
+  env.engine.set_positions(np.full((32, 3), 0.5), np.full((32, 3), 0.5))
+  ts = env.step(a)
+  moved = ts.observation['factors'][:, 2, 0].cpu().numpy() - 0.5
+  hit = moved != 0                      # a noised click may miss the sprite
+  assert hit.sum() >= 8 and np.all(np.abs(moved[hit] - 0.1) < 0.1) and np.std(moved[hit]) > 1e-3
   env.close()
