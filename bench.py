@@ -160,13 +160,13 @@ def main():
     raise SystemExit('launch with torch.distributed.run for --gpus > 1')
   barrier = None
   dist = None
-  if world > 1:
+  if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:   # launched by torch.distributed.run
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     torch.cuda.set_device(local_rank)
     dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     barrier = dist.barrier
-  device = local_rank if world > 1 else 0
+  device = local_rank if dist is not None else 0
 
   res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
                 barrier=barrier, seed=rank)
