@@ -111,10 +111,6 @@ def davies_bouldin(pos_f32, x, y, label):
   return err, out.value
 
 
-def set_fma_dot(flag):
-  lib().swo_set_fma_dot(int(flag))
-
-
 def render_sprites(cfg, x, y, shape, scale, cos_a, sin_a, rgb):
   """One frame (PILRenderer.render) for explicit sprite arrays."""
   n = len(x)

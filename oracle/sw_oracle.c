@@ -514,7 +514,6 @@ static void task_find_goal(const swb_task* t, int n, const double* x, const doub
  *   X @ X.T (syrk/gemm), x.dot(x) (ddot)                      fma(a1, b1, a0*b0)
  * For float32 positions (the config-sampled case) every product of two upcast float32 values
  * is exact in float64, so all of these orders give identical results. */
-void swo_set_fma_dot(int v) { (void)v; }
 static double norm2(double a0, double a1) { return a0 * a0 + a1 * a1; }
 static double dot2_hi(double a0, double a1, double b0, double b1) { return fma(a1, b1, a0 * b0); }
 static double dot2_lo(double a0, double a1, double b0, double b1) { return fma(a0, b0, a1 * b1); }

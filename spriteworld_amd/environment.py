@@ -43,7 +43,7 @@ class BatchedEnvironment(object):
 
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, num_envs=1, episodes_per_env=8,
-               max_sprites=None, device=0, check_errors=True, action_dtype=np.float64):
+               max_sprites=None, device=0, check_errors=32, action_dtype=np.float64):
     self._task = task
     self._action_space = action_space
     self._renderers = renderers
@@ -53,7 +53,11 @@ class BatchedEnvironment(object):
     self._metadata = metadata
     self._num_envs = int(num_envs)
     self._episodes_per_env = int(episodes_per_env)
-    self._check_errors = check_errors
+    # Per-environment error flags (conditions that make the reference raise) are read back every
+    # `check_errors` steps (True/1: every step, which costs a device sync per step; 0/False: never;
+    # `check()` can be called at any time).
+    self._check_errors = int(check_errors)
+    self._steps_since_check = 0
     self._image_key, self._pil = lowering.find_pil_renderer(renderers)
     self._success_keys = [k for k, r in renderers.items() if type(r).__name__ == 'Success']
     self._factor_keys = {k: r for k, r in renderers.items() if type(r).__name__ == 'SpriteFactors'}
@@ -118,13 +122,9 @@ class BatchedEnvironment(object):
   def _timestep(self):
     e = self._engine
     if self._check_errors:
-      err = int(e.error.max().item())
-      if err:
-        if err & _abi.ENV_ERR_DB_ZERO:
-          raise ZeroDivisionError('float division by zero (Davies-Bouldin score is 0)')
-        if err & _abi.ENV_ERR_DB_LABELS:
-          raise ValueError('Number of labels is invalid for davies_bouldin_score')
-        raise EnvironmentError_('internal engine error bits 0x%x' % err)
+      self._steps_since_check += 1
+      if self._steps_since_check >= self._check_errors:
+        self.check()
     obs = {}
     if self._image_key is not None:
       obs[self._image_key] = e.obs
@@ -146,6 +146,17 @@ class BatchedEnvironment(object):
     """Seeds the generator of the SelectMove action noise."""
     self._noise_gen = torch.Generator(device=self._engine.device)
     self._noise_gen.manual_seed(int(seed))
+
+  def check(self):
+    """Raises what the reference would have raised if any environment flagged an error."""
+    self._steps_since_check = 0
+    err = int(self._engine.error.max().item())
+    if err:
+      if err & _abi.ENV_ERR_DB_ZERO:
+        raise ZeroDivisionError('float division by zero (Davies-Bouldin score is 0)')
+      if err & _abi.ENV_ERR_DB_LABELS:
+        raise ValueError('Number of labels is invalid for davies_bouldin_score')
+      raise EnvironmentError_('internal engine error bits 0x%x' % err)
 
   def reset(self):
     """Environment.reset() for every environment: returns the FIRST time steps."""
@@ -199,7 +210,7 @@ class Environment(object):
     self._batched = BatchedEnvironment(
         task, action_space, renderers, init_sprites, keep_in_frame=keep_in_frame,
         max_episode_length=max_episode_length, metadata=metadata, num_envs=1,
-        episodes_per_env=episodes_per_pool, device=device, action_dtype=action_dtype)
+        episodes_per_env=episodes_per_pool, device=device, action_dtype=action_dtype, check_errors=1)
     self._episodes_per_pool = episodes_per_pool
     self._episodes_used = 0
     self._reset_next_step = True
