@@ -145,6 +145,57 @@ typedef struct swb_pool {
   const double* color;        /* [P,S,3] c0,c1,c2; only for swb_factors (may be NULL) */
 } swb_pool;
 
+/* Device-side reset sampling: a declarative form of the sprite
+ * generators the shipped configs build from Product-of-Continuous/Discrete factor distributions
+ * (factor_distributions.py:81-158,268-310; sprite_generators.py:27-70,101-128).  Each group draws
+ * `count` sprites (uniform integer in [count_min, count_max]) whose factors are independent; the
+ * groups are concatenated in order and the z-order optionally shuffled.  Sampling uses a
+ * counter-based Philox4x32-10 stream per pool entry: statistically, not bitwise, equivalent to the
+ * reference's global MT19937 draws.  The value TYPES follow the reference exactly: a Continuous
+ * factor is np.random.uniform(lo, hi) cast to its dtype (float32 by default, or an integer type),
+ * a Discrete factor yields the Python object from its candidate list (a Python float). */
+#define SWB_MAX_GROUPS 8
+#define SWB_MAX_CANDIDATES 12
+enum swb_factor_kind {
+  SWB_FACTOR_UNIFORM_F32 = 0, /* Continuous(key, lo, hi)                 -> np.float32     */
+  SWB_FACTOR_UNIFORM_INT = 1, /* Continuous(key, lo, hi, dtype='int32')  -> truncated int  */
+  SWB_FACTOR_DISCRETE = 2     /* Discrete(key, candidates)               -> Python float   */
+};
+typedef struct swb_factor {
+  int32_t kind;
+  int32_t n;                          /* candidates (SWB_FACTOR_DISCRETE)                  */
+  double lo, hi;                      /* [lo, hi)   (uniform kinds)                        */
+  double cand[SWB_MAX_CANDIDATES];
+} swb_factor;
+enum swb_factor_index {
+  SWB_F_X = 0, SWB_F_Y, SWB_F_SCALE, SWB_F_ANGLE, SWB_F_C0, SWB_F_C1, SWB_F_C2, SWB_F_XVEL, SWB_F_YVEL, SWB_N_FACTORS
+};
+/* SetMinus(base, hold_out) (factor_distributions.py:313-344): the factors in `redraw_mask` (base.keys)
+ * are redrawn until they leave the box  AND_k lo[k] <= value_k < hi[k]  over `box_mask`. */
+#define SWB_MAX_HOLDOUTS 2
+typedef struct swb_holdout {
+  uint32_t redraw_mask, box_mask;     /* bit i = factor index i                            */
+  double lo[SWB_N_FACTORS], hi[SWB_N_FACTORS];
+} swb_holdout;
+typedef struct swb_sprite_group {
+  int32_t count_min, count_max;
+  /* x, y: UNIFORM_F32 only (float32 positions); angle: DISCRETE, or UNIFORM_INT within [0, 360] */
+  swb_factor factors[SWB_N_FACTORS];
+  int32_t n_holdouts, reserved;
+  swb_holdout holdouts[SWB_MAX_HOLDOUTS];
+  int32_t n_shapes, shapes[SWB_MAX_CANDIDATES];                /* shape table indices      */
+  double cos_a[SWB_MAX_CANDIDATES], sin_a[SWB_MAX_CANDIDATES]; /* of angle.cand (radians)  */
+  int8_t label[SWB_MAX_TASKS];                                 /* task label of the group  */
+} swb_sprite_group;
+typedef struct swb_sampler {
+  int32_t n_groups;
+  int32_t shuffle;          /* sprite_generators.shuffle                                   */
+  int32_t color_map;        /* 0: (c0,c1,c2) are RGB ints; 1: renderers.color_maps.hsv_to_rgb */
+  int32_t reserved;
+  double deg_cos[360], deg_sin[360]; /* math.cos/sin(math.radians(d)) for integer degrees  */
+  swb_sprite_group groups[SWB_MAX_GROUPS];
+} swb_sampler;
+
 /* Per-step outputs, device memory, caller-owned.  Any pointer may be NULL. */
 typedef struct swb_outputs {
   uint8_t* obs;        /* u8 [N, H, W, 3]  PILRenderer.render (pil_renderer.py:67-91)      */
@@ -187,6 +238,15 @@ int swb_upload_resample(swb_handle h, int32_t axis /*0=horizontal,1=vertical*/, 
 /* Install the reset pool and mark every environment "reset on next step"
  * (Environment.__init__, environment.py:68-70). */
 int swb_set_pool(swb_handle h, const swb_pool* pool);
+
+/* Fills a pool of `n_entries` episodes on the device from `spec` (no host sampling, no upload) and
+ * marks every environment "reset on next step", like swb_set_pool.  pool_base/pool_len: i32[N]. */
+int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, const int32_t* pool_base_host,
+                    const int32_t* pool_len_host, uint64_t seed, void* stream);
+
+/* Copies the device pool into caller-allocated HOST arrays laid out like swb_set_pool's input
+ * (pool->n_entries must equal the device pool's; angle/color may be NULL).  Synchronous. */
+int swb_get_pool(swb_handle h, const swb_pool* pool_host);
 
 /* Environment.reset() for all envs: the next swb_step is a FIRST step. */
 int swb_reset_all(swb_handle h, void* stream);

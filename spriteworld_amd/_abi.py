@@ -5,6 +5,8 @@ SWB_MAX_SPRITES = 16
 SWB_MAX_TASKS = 8
 SWB_MAX_SHAPES = 32
 SWB_MAX_SHAPE_VERTS = 64
+SWB_MAX_GROUPS = 8
+SWB_MAX_CANDIDATES = 12
 
 # enum swb_action_space
 ACTION_SELECT_MOVE, ACTION_DRAG_AND_DROP, ACTION_EMBODIED = 0, 1, 2
@@ -98,4 +100,63 @@ class SwbState(C.Structure):
       ('step_count', C.c_void_p),
       ('reset_next', C.c_void_p),
       ('episode', C.c_void_p),
+  ]
+
+
+FACTOR_UNIFORM_F32, FACTOR_UNIFORM_INT, FACTOR_DISCRETE = 0, 1, 2
+
+
+class SwbFactor(C.Structure):
+  _fields_ = [
+      ('kind', C.c_int32),
+      ('n', C.c_int32),
+      ('lo', C.c_double),
+      ('hi', C.c_double),
+      ('cand', C.c_double * SWB_MAX_CANDIDATES),
+  ]
+
+
+FACTOR_ORDER = ('x', 'y', 'scale', 'angle', 'c0', 'c1', 'c2', 'x_vel', 'y_vel')   # enum swb_factor_index
+SWB_N_FACTORS = len(FACTOR_ORDER)
+SWB_MAX_HOLDOUTS = 2
+
+
+class SwbHoldout(C.Structure):
+  _fields_ = [
+      ('redraw_mask', C.c_uint32),
+      ('box_mask', C.c_uint32),
+      ('lo', C.c_double * SWB_N_FACTORS),
+      ('hi', C.c_double * SWB_N_FACTORS),
+  ]
+
+
+class SwbSpriteGroup(C.Structure):
+
+  def factor(self, key):
+    return self.factors[FACTOR_ORDER.index(key)]
+
+  _fields_ = [
+      ('count_min', C.c_int32),
+      ('count_max', C.c_int32),
+      ('factors', SwbFactor * SWB_N_FACTORS),
+      ('n_holdouts', C.c_int32),
+      ('reserved', C.c_int32),
+      ('holdouts', SwbHoldout * SWB_MAX_HOLDOUTS),
+      ('n_shapes', C.c_int32),
+      ('shapes', C.c_int32 * SWB_MAX_CANDIDATES),
+      ('cos_a', C.c_double * SWB_MAX_CANDIDATES),
+      ('sin_a', C.c_double * SWB_MAX_CANDIDATES),
+      ('label', C.c_int8 * SWB_MAX_TASKS),
+  ]
+
+
+class SwbSampler(C.Structure):
+  _fields_ = [
+      ('n_groups', C.c_int32),
+      ('shuffle', C.c_int32),
+      ('color_map', C.c_int32),
+      ('reserved', C.c_int32),
+      ('deg_cos', C.c_double * 360),
+      ('deg_sin', C.c_double * 360),
+      ('groups', SwbSpriteGroup * SWB_MAX_GROUPS),
   ]

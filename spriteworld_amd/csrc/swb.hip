@@ -15,6 +15,7 @@
 
 #include "swb_kernels.hip.inc"
 #include "swb_pow.hip.inc"
+#include "swb_sampler.hip.inc"
 
 namespace {
 
@@ -68,6 +69,8 @@ struct swb_engine {
   int8_t* d_p_label = nullptr;
   int32_t *d_pool_base = nullptr, *d_pool_len = nullptr;
   double *d_p_angle = nullptr, *d_p_color = nullptr;
+  swb_sampler* d_sampler = nullptr;
+  int pool_entries = 0;
   double *d_x = nullptr, *d_y = nullptr;
   int32_t *d_nspr = nullptr, *d_entry = nullptr, *d_step_count = nullptr, *d_episode = nullptr;
   uint8_t* d_reset_next = nullptr;
@@ -240,7 +243,7 @@ int swb_destroy(swb_handle h) {
   void* bufs[] = {h->d_shape_verts, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
-                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_p_angle, h->d_p_color};
+                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_p_angle, h->d_p_color, h->d_sampler};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;
@@ -362,10 +365,116 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
   p.p_n = h->d_p_n; p.p_x = h->d_p_x; p.p_y = h->d_p_y; p.p_xv = h->d_p_xv; p.p_yv = h->d_p_yv;
   p.p_scale = h->d_p_scale; p.p_ca = h->d_p_ca; p.p_sa = h->d_p_sa; p.p_shape = h->d_p_shape; p.p_rgb = h->d_p_rgb;
   p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
+  h->pool_entries = P;
   HIP_TRY(hipMemset(h->d_reset_next, 1, N));      // environment.py:70
   HIP_TRY(hipMemset(h->d_episode, 0, sizeof(int32_t) * N));
   HIP_TRY(hipMemset(h->d_step_count, 0, sizeof(int32_t) * N));
   h->have_pool = true;
+  return SWB_OK;
+}
+
+int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, const int32_t* pool_base_host,
+                    const int32_t* pool_len_host, uint64_t seed, void* stream) {
+  if (!h || !spec || !pool_base_host || !pool_len_host) return fail(SWB_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const int P = n_entries, S = h->p.S, T = h->p.n_tasks, N = h->p.N;
+  if (P < 1) return fail(SWB_ERR_INVALID, "pool is empty");
+  if (spec->n_groups < 1 || spec->n_groups > SWB_MAX_GROUPS) return fail(SWB_ERR_INVALID, "n_groups must be in [1, %d]", SWB_MAX_GROUPS);
+  int max_total = 0;
+  for (int g = 0; g < spec->n_groups; ++g) {
+    const swb_sprite_group& grp = spec->groups[g];
+    if (grp.count_min < 0 || grp.count_max < grp.count_min) return fail(SWB_ERR_INVALID, "group %d: bad sprite count range", g);
+    if (grp.n_shapes < 1 || grp.n_shapes > SWB_MAX_CANDIDATES)
+      return fail(SWB_ERR_INVALID, "group %d: 1..%d shape candidates", g, SWB_MAX_CANDIDATES);
+    for (const swb_factor* f = grp.factors; f != grp.factors + SWB_N_FACTORS; ++f) {
+      if (f->kind < SWB_FACTOR_UNIFORM_F32 || f->kind > SWB_FACTOR_DISCRETE) return fail(SWB_ERR_INVALID, "group %d: bad factor kind", g);
+      if (f->kind == SWB_FACTOR_DISCRETE && (f->n < 1 || f->n > SWB_MAX_CANDIDATES))
+        return fail(SWB_ERR_INVALID, "group %d: Discrete factors take 1..%d candidates", g, SWB_MAX_CANDIDATES);
+    }
+    if (grp.factors[SWB_F_X].kind != SWB_FACTOR_UNIFORM_F32 || grp.factors[SWB_F_Y].kind != SWB_FACTOR_UNIFORM_F32)
+      return fail(SWB_ERR_INVALID, "group %d: x and y must be float32 Continuous factors", g);
+    const swb_factor& ang = grp.factors[SWB_F_ANGLE];
+    if (ang.kind == SWB_FACTOR_UNIFORM_F32 ||
+        (ang.kind == SWB_FACTOR_UNIFORM_INT && !(ang.lo >= 0.0 && ang.hi <= 360.0 && ang.lo <= ang.hi)))
+      return fail(SWB_ERR_INVALID, "group %d: angle must be Discrete or integer degrees within [0, 360]", g);
+    if (grp.n_holdouts < 0 || grp.n_holdouts > SWB_MAX_HOLDOUTS) return fail(SWB_ERR_INVALID, "group %d: at most %d hold-outs", g, SWB_MAX_HOLDOUTS);
+    for (int i = 0; i < grp.n_holdouts; ++i)
+      if (grp.holdouts[i].box_mask == 0 || (grp.holdouts[i].box_mask & ~grp.holdouts[i].redraw_mask) ||
+          (grp.holdouts[i].redraw_mask >> SWB_N_FACTORS))
+        return fail(SWB_ERR_INVALID, "group %d: hold-out keys must be a non-empty subset of the redrawn keys", g);
+    if (spec->color_map == 1 && (grp.factors[SWB_F_C0].kind == SWB_FACTOR_UNIFORM_INT || grp.factors[SWB_F_C1].kind == SWB_FACTOR_UNIFORM_INT ||
+                                 grp.factors[SWB_F_C2].kind == SWB_FACTOR_UNIFORM_INT))
+      return fail(SWB_ERR_INVALID, "group %d: hsv colours must be float factors", g);
+    for (int i = 0; i < grp.n_shapes; ++i)
+      if (grp.shapes[i] < 0 || grp.shapes[i] >= SWB_MAX_SHAPES) return fail(SWB_ERR_INVALID, "group %d: bad shape index", g);
+    max_total += grp.count_max;
+  }
+  if (max_total > S) return fail(SWB_ERR_INVALID, "sampler can emit %d sprites (max_sprites %d)", max_total, S);
+  for (int i = 0; i < N; ++i)
+    if (pool_len_host[i] < 1 || pool_base_host[i] < 0 || pool_base_host[i] + pool_len_host[i] > P)
+      return fail(SWB_ERR_INVALID, "env %d: pool range [%d, +%d) outside the pool of %d", i, pool_base_host[i], pool_len_host[i], P);
+  const size_t PS = (size_t)P * S;
+  int rc = 0;
+  if (h->pool_entries != P || !h->d_p_angle || !h->d_p_color) {
+    rc |= upload<int32_t>(&h->d_p_n, nullptr, P);
+    rc |= upload<double>(&h->d_p_x, nullptr, PS); rc |= upload<double>(&h->d_p_y, nullptr, PS);
+    rc |= upload<double>(&h->d_p_xv, nullptr, PS); rc |= upload<double>(&h->d_p_yv, nullptr, PS);
+    rc |= upload<double>(&h->d_p_scale, nullptr, PS); rc |= upload<double>(&h->d_p_ca, nullptr, PS);
+    rc |= upload<double>(&h->d_p_sa, nullptr, PS);
+    rc |= upload<int32_t>(&h->d_p_shape, nullptr, PS); rc |= upload<uint32_t>(&h->d_p_rgb, nullptr, PS);
+    rc |= upload<int8_t>(&h->d_p_label, nullptr, (size_t)P * T * S);
+    rc |= upload<double>(&h->d_p_angle, nullptr, PS); rc |= upload<double>(&h->d_p_color, nullptr, PS * 3);
+  }
+  rc |= upload(&h->d_pool_base, pool_base_host, N);
+  rc |= upload(&h->d_pool_len, pool_len_host, N);
+  rc |= upload(&h->d_sampler, spec, 1);
+  if (rc) return SWB_ERR_HIP;
+  h->pool_entries = P;
+  swb_params& p = h->p;
+  p.p_n = h->d_p_n; p.p_x = h->d_p_x; p.p_y = h->d_p_y; p.p_xv = h->d_p_xv; p.p_yv = h->d_p_yv;
+  p.p_scale = h->d_p_scale; p.p_ca = h->d_p_ca; p.p_sa = h->d_p_sa; p.p_shape = h->d_p_shape; p.p_rgb = h->d_p_rgb;
+  p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
+  p.p_angle = h->d_p_angle; p.p_color = h->d_p_color;
+  swb_sampler_args a{h->d_sampler, P, S, T, seed, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale,
+                     h->d_p_ca, h->d_p_sa, h->d_p_angle, h->d_p_color, h->d_p_shape, h->d_p_rgb, h->d_p_label};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(swb_sample_pool_kernel, dim3((P + 255) / 256), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(h->d_reset_next, 1, N, st));      // environment.py:70
+  HIP_TRY(hipMemsetAsync(h->d_episode, 0, sizeof(int32_t) * N, st));
+  HIP_TRY(hipMemsetAsync(h->d_step_count, 0, sizeof(int32_t) * N, st));
+  h->have_pool = true;
+  return SWB_OK;
+}
+
+int swb_get_pool(swb_handle h, const swb_pool* pool) {
+  if (!h || !pool) return fail(SWB_ERR_INVALID, "null argument");
+  if (!h->have_pool) return fail(SWB_ERR_STATE, "no pool on the device");
+  if (pool->n_entries != h->pool_entries) return fail(SWB_ERR_INVALID, "pool has %d entries, not %d", h->pool_entries, pool->n_entries);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int P = h->pool_entries, S = h->p.S, T = h->p.n_tasks, N = h->p.N;
+  const size_t PS = (size_t)P * S;
+#define SWB_D2H(dst, src, count) \
+  if (dst) HIP_TRY(hipMemcpy((void*)(dst), (src), (count) * sizeof(*(src)), hipMemcpyDeviceToHost))
+  SWB_D2H(pool->n_sprites, h->d_p_n, (size_t)P);
+  SWB_D2H(pool->x, h->d_p_x, PS); SWB_D2H(pool->y, h->d_p_y, PS);
+  SWB_D2H(pool->x_vel, h->d_p_xv, PS); SWB_D2H(pool->y_vel, h->d_p_yv, PS);
+  SWB_D2H(pool->scale, h->d_p_scale, PS); SWB_D2H(pool->cos_a, h->d_p_ca, PS); SWB_D2H(pool->sin_a, h->d_p_sa, PS);
+  SWB_D2H(pool->shape, h->d_p_shape, PS);
+  SWB_D2H(pool->label, h->d_p_label, (size_t)P * T * S);
+  SWB_D2H(pool->pool_base, h->d_pool_base, (size_t)N); SWB_D2H(pool->pool_len, h->d_pool_len, (size_t)N);
+  if (h->p.p_angle) SWB_D2H(pool->angle, h->d_p_angle, PS);
+  if (h->p.p_color) SWB_D2H(pool->color, h->d_p_color, PS * 3);
+  if (pool->rgb) {
+    std::vector<uint32_t> rgb(PS);
+    HIP_TRY(hipMemcpy(rgb.data(), h->d_p_rgb, PS * 4, hipMemcpyDeviceToHost));
+    uint8_t* dst = const_cast<uint8_t*>(pool->rgb);
+    for (size_t i = 0; i < PS; ++i) {
+      dst[4 * i] = rgb[i] & 255; dst[4 * i + 1] = (rgb[i] >> 8) & 255; dst[4 * i + 2] = (rgb[i] >> 16) & 255; dst[4 * i + 3] = 0;
+    }
+  }
+#undef SWB_D2H
   return SWB_OK;
 }
 

@@ -1,0 +1,232 @@
+"""Declarative sprite generator that the engine can sample on the device (swb_sample_pool).
+
+The reference's `init_sprites` is an opaque Python callable (environment.py:68,75), so resets cost
+host time per episode.  Every shipped config builds it from
+`generate_sprites(Product([Continuous/Discrete ...]), num_sprites)` groups that are chained and
+optionally shuffled (sprite_generators.py:27-70,101-128).  `DeviceSampler` takes those same
+ingredients, keeps them inspectable, and lowers them to `swb_sampler` (include/swb.h):
+
+    sampler = DeviceSampler([(target_factors, 2), (distractor_factors, (1, 4))], shuffle=True)
+    env = BatchedEnvironment(init_sprites=sampler, ...)      # pool drawn by a HIP kernel
+    env.refill_pool()                                        # fresh episodes, no host work
+
+Calling the object samples on the host with numpy (same marginals), so it is also a valid
+`init_sprites` for the reference's own Environment.  Device draws come from Philox4x32-10 streams:
+the distribution is the reference's, the bit stream is not MT19937's.
+"""
+import math
+
+import numpy as np
+
+from spriteworld_amd import _abi
+from spriteworld_amd import shapes as _shapes
+from spriteworld_amd import sprite as sprite_lib
+from spriteworld_amd.lowering import LoweringError, subtasks_of, _label_of
+
+_FACTOR_KEYS = _abi.FACTOR_ORDER
+_DEFAULTS = dict(x=0.5, y=0.5, shape='square', angle=0, scale=0.1, c0=0, c1=0, c2=0, x_vel=0.0, y_vel=0.0)
+
+
+def _lower_factor(dst, key, leaf):
+  """Continuous / Discrete leaf (or None: the Sprite default) -> swb_factor."""
+  if leaf is None:
+    dst.kind, dst.n = _abi.FACTOR_DISCRETE, 1
+    dst.cand[0] = float(_DEFAULTS[key])
+    return [_DEFAULTS[key]]
+  if type(leaf).__name__ == 'Continuous':
+    dt = np.dtype(leaf.dtype)
+    if dt == np.float32:
+      dst.kind = _abi.FACTOR_UNIFORM_F32
+    elif dt.kind in 'iu':
+      dst.kind = _abi.FACTOR_UNIFORM_INT
+    else:
+      raise LoweringError('factor %s: dtype %s is not sampled on the device' % (key, dt))
+    dst.lo, dst.hi = float(leaf.minval), float(leaf.maxval)
+    return None
+  if getattr(leaf, 'probs', None) is not None:
+    raise LoweringError('factor %s: weighted Discrete factors are not sampled on the device' % key)
+  cands = list(leaf.candidates)
+  if not 1 <= len(cands) <= _abi.SWB_MAX_CANDIDATES:
+    raise LoweringError('factor %s: 1..%d candidates' % (key, _abi.SWB_MAX_CANDIDATES))
+  if not all(type(c) in (float, int) for c in cands):
+    raise LoweringError('factor %s: Discrete candidates must be Python floats or ints' % key)
+  dst.kind, dst.n = _abi.FACTOR_DISCRETE, len(cands)
+  for i, c in enumerate(cands):
+    dst.cand[i] = float(c)
+  return cands
+
+
+def _box_of(dist):
+  """A hold-out region as {key: (lo, hi)}: a Continuous leaf or a Product of them."""
+  name = type(dist).__name__
+  if name == 'Continuous':
+    return {dist.key: (float(dist.minval), float(dist.maxval))}
+  if name == 'Product':
+    out = {}
+    for c in dist.components:
+      out.update(_box_of(c))
+    return out
+  raise LoweringError('hold-out regions must be Continuous ranges (got %s)' % name)
+
+
+def _marginals(dist, holdouts=None):
+  """Flattens a Product / SetMinus tree of Continuous/Discrete leaves into {key: leaf}.
+
+  SetMinus nodes append (redrawn keys, {key: (lo, hi)}) to `holdouts`."""
+  name = type(dist).__name__
+  if name == 'Product':
+    out = {}
+    for c in dist.components:
+      sub = _marginals(c, holdouts)
+      if set(sub) & set(out):
+        raise LoweringError('factor %s appears twice' % sorted(set(sub) & set(out)))
+      out.update(sub)
+    return out
+  if name in ('Continuous', 'Discrete'):
+    return {dist.key: dist}
+  if name == 'SetMinus' and holdouts is not None:
+    inner = []
+    out = _marginals(dist.base, inner)
+    if inner:
+      raise LoweringError('nested SetMinus distributions are not sampled on the device')
+    holdouts.append((sorted(out), _box_of(dist.hold_out)))
+    return out
+  raise LoweringError('%s cannot be sampled on the device (Product / SetMinus / Continuous / Discrete)' % name)
+
+
+class DeviceSampler(object):
+  """`groups`: list of (factor_distribution, num_sprites); num_sprites is an int or a (lo, hi)
+  pair meaning np.random.randint(lo, hi).  `shuffle`: sprite_generators.shuffle of the z-order."""
+
+  def __init__(self, groups, shuffle=False, seed=0):
+    self.groups, self._holdouts = [], []
+    for dist, count in groups:
+      if isinstance(count, (tuple, list)):
+        lo, hi = int(count[0]), int(count[1]) - 1
+      else:
+        lo = hi = int(count)
+      if lo < 0 or hi < lo:
+        raise ValueError('bad sprite count %r' % (count,))
+      holdouts = []
+      marg = _marginals(dist, holdouts)
+      if len(holdouts) > _abi.SWB_MAX_HOLDOUTS:
+        raise LoweringError('at most %d SetMinus nodes per sprite group' % _abi.SWB_MAX_HOLDOUTS)
+      self.groups.append((dist, lo, hi, marg))
+      self._holdouts.append(holdouts)
+    if not 1 <= len(self.groups) <= _abi.SWB_MAX_GROUPS:
+      raise LoweringError('1..%d sprite groups are supported' % _abi.SWB_MAX_GROUPS)
+    self.shuffle = bool(shuffle)
+    self.seed = int(seed)
+    self._draws = 0
+
+  @property
+  def max_sprites(self):
+    return sum(hi for _, _, hi, _ in self.groups)
+
+  def next_seed(self):
+    """A fresh 64-bit Philox key per pool (splitmix64 of seed and draw counter)."""
+    z = (self.seed * 0x9E3779B97F4A7C15 + self._draws + 1) & 0xFFFFFFFFFFFFFFFF
+    self._draws += 1
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+  # ---------------------------------------------------------------- host sampling (numpy)
+  def __call__(self):
+    sprites = []
+    for dist, lo, hi, _ in self.groups:
+      n = lo if lo == hi else np.random.randint(lo, hi + 1)
+      sprites.extend(sprite_lib.Sprite(**dist.sample()) for _ in range(n))
+    if self.shuffle:
+      order = np.random.permutation(len(sprites))
+      sprites = [sprites[i] for i in order]
+    return sprites
+
+  # ---------------------------------------------------------------- lowering
+  def _group_label(self, sub, dist, marg):
+    """Task label of a group's sprites; must not depend on the sampled values."""
+    probes = [dist.sample() for _ in range(256)]
+    for key, leaf in marg.items():  # range ends of every continuous factor
+      if type(leaf).__name__ == 'Continuous' and leaf.maxval > leaf.minval:
+        if np.dtype(leaf.dtype) == np.float32:
+          lo = np.float32(leaf.minval)
+          hi = np.nextafter(np.float32(leaf.maxval), np.float32(-np.inf))
+        else:
+          lo = np.asarray(leaf.minval).astype(leaf.dtype)
+          hi = np.asarray(np.nextafter(float(leaf.maxval), -np.inf)).astype(leaf.dtype)
+        for v in (lo, hi):
+          f = dist.sample()
+          f[key] = v
+          probes.append(f)
+    labels = set()
+    for f in probes:
+      full = dict(_DEFAULTS)
+      full.update(f)
+      labels.add(_label_of(sub, sprite_lib.Sprite(**full)))
+    if len(labels) != 1:
+      raise LoweringError('task label of a sprite group depends on the sampled factors (%s): sample this '
+                          'generator on the host instead' % sorted(labels))
+    return labels.pop()
+
+  def lower(self, task, renderers):
+    from spriteworld_amd import lowering
+    spec = _abi.SwbSampler()
+    spec.n_groups = len(self.groups)
+    spec.shuffle = int(self.shuffle)
+    _, pil = lowering.find_pil_renderer(renderers)
+    to_rgb = getattr(pil, '_color_to_rgb', None) if pil is not None else None
+    probe = (0.3, 0.6, 0.9)
+    if to_rgb is None or tuple(to_rgb(probe)) == probe:
+      spec.color_map = 0
+    elif getattr(to_rgb, '__name__', '') == 'hsv_to_rgb':
+      spec.color_map = 1
+    else:
+      raise LoweringError('color_to_rgb %r is not available on the device (identity or hsv_to_rgb)' % (to_rgb,))
+    for d in range(360):  # sprite.py:147-151 rotates by radians of the stored degrees
+      spec.deg_cos[d], spec.deg_sin[d] = math.cos(math.radians(d)), math.sin(math.radians(d))
+    subs = subtasks_of(task)
+    for g, (dist, lo, hi, marg) in enumerate(self.groups):
+      grp = spec.groups[g]
+      grp.count_min, grp.count_max = lo, hi
+      unknown = set(marg) - set(_FACTOR_KEYS) - {'shape'}
+      if unknown:
+        raise LoweringError('unknown sprite factors %s' % sorted(unknown))
+      for key in _FACTOR_KEYS:
+        fac = grp.factor(key)
+        cands = _lower_factor(fac, key, marg.get(key))
+        if key in ('x', 'y') and fac.kind != _abi.FACTOR_UNIFORM_F32:
+          raise LoweringError('%s must be a float32 Continuous factor' % key)
+        if key == 'angle':
+          if fac.kind == _abi.FACTOR_UNIFORM_F32 or (
+              fac.kind == _abi.FACTOR_UNIFORM_INT and not 0 <= fac.lo <= fac.hi <= 360):
+            raise LoweringError('angle must be Discrete or integer degrees within [0, 360]')
+          for i, c in enumerate(cands or []):
+            grp.cos_a[i], grp.sin_a[i] = math.cos(math.radians(c)), math.sin(math.radians(c))
+        if spec.color_map == 1 and key in ('c0', 'c1', 'c2') and fac.kind == _abi.FACTOR_UNIFORM_INT:
+          raise LoweringError('hsv colours must be float factors')
+      grp.n_holdouts = len(self._holdouts[g])
+      for i, (redrawn, box) in enumerate(self._holdouts[g]):
+        ho = grp.holdouts[i]
+        if 'shape' in box:
+          raise LoweringError('hold-out regions over shape are not sampled on the device')
+        ho.redraw_mask = sum(1 << _abi.FACTOR_ORDER.index(k) for k in redrawn if k != 'shape')
+        ho.box_mask = sum(1 << _abi.FACTOR_ORDER.index(k) for k in box)
+        for k, (blo, bhi) in box.items():
+          ho.lo[_abi.FACTOR_ORDER.index(k)], ho.hi[_abi.FACTOR_ORDER.index(k)] = blo, bhi
+        if 'shape' in redrawn:
+          raise LoweringError('SetMinus over a base that includes shape is not sampled on the device')
+      leaf = marg.get('shape')
+      if leaf is None:
+        names = [_DEFAULTS['shape']]
+      elif type(leaf).__name__ == 'Discrete' and getattr(leaf, 'probs', None) is None:
+        names = list(leaf.candidates)
+      else:
+        raise LoweringError('shape must be an unweighted Discrete factor')
+      if not 1 <= len(names) <= _abi.SWB_MAX_CANDIDATES:
+        raise LoweringError('shape: 1..%d candidates' % _abi.SWB_MAX_CANDIDATES)
+      grp.n_shapes = len(names)
+      for i, name in enumerate(names):
+        grp.shapes[i] = _shapes.shape_index(name)
+      for t, sub in enumerate(subs):
+        grp.label[t] = self._group_label(sub, dist, marg)
+    return spec

@@ -43,7 +43,9 @@ class Engine(object):
         coeffs = np.ascontiguousarray(coeffs)
         _lib.check(self.lib.swb_upload_resample(self._h, axis, out_size, coeffs.shape[1],
                                                 _ptr(bounds), _ptr(coeffs)))
-    self.set_pool(pool)
+    self.pool = None
+    if pool is not None:
+      self.set_pool(pool)
     with torch.cuda.device(self.device):
       self.obs = torch.zeros((self.N,) + self.obs_shape, dtype=torch.uint8, device=self.device)
       self.reward = torch.zeros(self.N, dtype=torch.float64, device=self.device)
@@ -83,6 +85,27 @@ class Engine(object):
     self.pool = pool
     cpool = pool.as_struct()
     _lib.check(self.lib.swb_set_pool(self._h, C.byref(cpool)))
+
+  def sample_pool(self, spec, n_entries, pool_base, pool_len, seed):
+    """Draws `n_entries` episodes on the device from an _abi.SwbSampler (swb_sample_pool)."""
+    base = np.ascontiguousarray(pool_base, dtype=np.int32)
+    length = np.ascontiguousarray(pool_len, dtype=np.int32)
+    assert base.shape == (self.N,) and length.shape == (self.N,)
+    _lib.check(self.lib.swb_sample_pool(self._h, C.byref(spec), int(n_entries), _ptr(base), _ptr(length),
+                                        C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), self._stream()))
+    self.pool = None
+    self._pool_entries = int(n_entries)
+
+  def get_pool(self):
+    """Host copy (lowering.Pool) of the pool the device currently holds."""
+    from spriteworld_amd import lowering
+    n = self.pool.n_entries if self.pool is not None else self._pool_entries
+    pool = lowering.Pool(n, self.S, self.cfg.n_tasks)
+    pool.pool_base = np.zeros(self.N, np.int32)
+    pool.pool_len = np.zeros(self.N, np.int32)
+    cpool = pool.as_struct()
+    _lib.check(self.lib.swb_get_pool(self._h, C.byref(cpool)))
+    return pool
 
   def reset_all(self):
     _lib.check(self.lib.swb_reset_all(self._h, self._stream()))

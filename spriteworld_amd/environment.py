@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from spriteworld_amd import _abi
+from spriteworld_amd import device_sampler
 from spriteworld_amd import dm_env_compat as dm_env
 from spriteworld_amd import engine as _engine
 from spriteworld_amd import lowering
@@ -65,10 +66,16 @@ class BatchedEnvironment(object):
                    if k != self._image_key and k not in self._success_keys and k not in self._factor_keys]
     if unsupported:
       raise lowering.LoweringError('renderers not supported on device: %s' % unsupported)
-    episodes = self._draw_episodes()
-    S = max_sprites or max([len(ep) for ep in episodes] + [1])
+    self._sampler = init_sprites if isinstance(init_sprites, device_sampler.DeviceSampler) else None
+    if self._sampler is not None:   # episodes are drawn by the engine (swb_sample_pool)
+      episodes = None
+      S = max_sprites or max(self._sampler.max_sprites, 1)
+      pos_dt = np.float32
+    else:
+      episodes = self._draw_episodes()
+      S = max_sprites or max([len(ep) for ep in episodes] + [1])
+      pos_dt = lowering.position_dtype(episodes)
     self._max_sprites = S
-    pos_dt = lowering.position_dtype(episodes)
     self._cfg = lowering.lower_config(task, action_space, renderers, keep_in_frame,
                                       max_episode_length, self._num_envs, S,
                                       pos_is_f32=(pos_dt == np.float32), action_dtype=action_dtype)
@@ -76,9 +83,14 @@ class BatchedEnvironment(object):
     ns = getattr(action_space, '_noise_scale', None)
     self._noise_scale = None if not ns else torch.as_tensor(np.asarray(ns, dtype=np.float64))
     self._noise_gen = None
-    pool = lowering.lower_episodes(episodes, task, renderers, max_sprites=S)
-    pool.assign_round_robin(self._num_envs, self._episodes_per_env)
-    self._engine = _engine.Engine(self._cfg, pool, device=device)
+    if self._sampler is not None:
+      self._sampler_spec = self._sampler.lower(task, renderers)
+      self._engine = _engine.Engine(self._cfg, None, device=device)
+      self.refill_pool()
+    else:
+      pool = lowering.lower_episodes(episodes, task, renderers, max_sprites=S)
+      pool.assign_round_robin(self._num_envs, self._episodes_per_env)
+      self._engine = _engine.Engine(self._cfg, pool, device=device)
     self._render = self._pil is not None
 
   # ------------------------------------------------------------------ pool
@@ -86,7 +98,15 @@ class BatchedEnvironment(object):
     return [list(self._init_sprites()) for _ in range(self._num_envs * self._episodes_per_env)]
 
   def refill_pool(self):
-    """Draws a fresh pool with init_sprites(); every environment restarts (next step is FIRST)."""
+    """Draws a fresh pool with init_sprites(); every environment restarts (next step is FIRST).
+
+    With a DeviceSampler the pool is drawn by a HIP kernel (no host sampling, no upload)."""
+    if self._sampler is not None:
+      k = self._episodes_per_env
+      base = np.arange(self._num_envs, dtype=np.int32) * k
+      self._engine.sample_pool(self._sampler_spec, self._num_envs * k, base,
+                               np.full(self._num_envs, k, np.int32), self._sampler.next_seed())
+      return
     episodes = self._draw_episodes()
     pool = lowering.lower_episodes(episodes, self._task, self._renderers,
                                    max_sprites=self._max_sprites)

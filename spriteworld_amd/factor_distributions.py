@@ -105,13 +105,14 @@ class Intersection(object):
 
 
 class SetMinus(object):
-  """`hold_in` with the support of `hold_out` removed (rejection sampling)."""
+  """`base` with the support of `hold_out` removed (rejection sampling)."""
 
-  def __init__(self, hold_in, hold_out):
-    if not hold_out.keys <= hold_in.keys:
-      raise ValueError('keys of hold_out must be a subset of those of hold_in')
-    self.hold_in, self.hold_out = hold_in, hold_out
-    self.keys = set(hold_in.keys)
+  def __init__(self, base, hold_out):
+    if not hold_out.keys <= base.keys:
+      raise ValueError('keys of hold_out must be a subset of those of base')
+    self.base, self.hold_out = base, hold_out
+    self.hold_in = base
+    self.keys = set(base.keys)
 
   def sample(self, rng=None):
     for _ in range(_MAX_TRIES):

@@ -1,0 +1,302 @@
+"""Device-side reset sampling (swb_sample_pool): lowering on CPU, bit-for-bit draws on the GPU."""
+import numpy as np
+import pytest
+
+from spriteworld_amd import _abi
+from spriteworld_amd import action_spaces
+from spriteworld_amd import device_sampler
+from spriteworld_amd import factor_distributions as distribs
+from spriteworld_amd import lowering
+from spriteworld_amd import renderers as renderer_lib
+from spriteworld_amd import shapes
+from spriteworld_amd import sprite as sprite_lib
+from spriteworld_amd import tasks
+
+from tests import _sampler_model
+
+
+def _cobra_like(shuffle=True):
+  """Goal-finding with distractors in the style of configs/cobra/goal_finding_more_distractors.py."""
+  common = [distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9),
+            distribs.Discrete('shape', ['square', 'triangle', 'circle']), distribs.Discrete('scale', [0.13]),
+            distribs.Continuous('c1', 0.3, 1.), distribs.Continuous('c2', 0.9, 1.)]
+  target = distribs.Product(common + [distribs.Continuous('c0', 0., 0.4)])
+  distractor = distribs.Product(common + [distribs.Continuous('c0', 0.5, 0.9)])
+  sampler = device_sampler.DeviceSampler([(target, 2), (distractor, (1, 4))], shuffle=shuffle, seed=7)
+  task = tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.4), terminate_distance=0.1)
+  rend = {'image': renderer_lib.PILRenderer(image_size=(64, 64), anti_aliasing=5,
+                                            color_to_rgb=renderer_lib.color_maps.hsv_to_rgb),
+          'success': renderer_lib.Success()}
+  return sampler, task, rend
+
+
+def _mixed_types():
+  """Every factor kind: integer colours/angles, Python-float Discrete colours, Continuous scale, velocities."""
+  a = distribs.Product([
+      distribs.Continuous('x', 0.2, 0.8), distribs.Continuous('y', 0.2, 0.8),
+      distribs.Discrete('shape', ['star_5', 'spoke_4', 'pentagon', 'hexagon']),
+      distribs.Continuous('scale', 0.05, 0.15), distribs.Continuous('angle', 0, 360, dtype='int32'),
+      distribs.Continuous('c0', 64, 256, dtype='uint8'), distribs.Continuous('c1', 0, 128, dtype='int32'),
+      distribs.Discrete('c2', [255, 128, 7]),
+      distribs.Continuous('x_vel', -0.03, 0.03), distribs.Continuous('y_vel', -0.03, 0.03)])
+  b = distribs.Product([
+      distribs.Continuous('x', 0.0, 1.0), distribs.Continuous('y', 0.0, 1.0),
+      distribs.Discrete('angle', [0, 30, 45.5, 270]), distribs.Discrete('scale', [0.07, 0.2]),
+      distribs.Continuous('c0', 192, 256, dtype='int32')])
+  sampler = device_sampler.DeviceSampler([(a, (0, 3)), (b, 2), (a, 1)], shuffle=True, seed=3)
+  clusters = [distribs.Continuous('c1', 0, 128, dtype='int32'), distribs.Discrete('c1', [0])]
+  task = tasks.MetaAggregated((tasks.Clustering(clusters, terminate_bonus=0., reward_range=10.),
+                               tasks.FindGoalPosition(terminate_distance=0.05)), reward_aggregator='sum')
+  rend = {'image': renderer_lib.PILRenderer(image_size=(64, 64), anti_aliasing=2)}
+  return sampler, task, rend
+
+
+def _hsv_mixed():
+  """hsv colour map over mixed np.float32 / Python-float channels (NEP 50 promotion inside colorsys)."""
+  groups = []
+  for c0, c1, c2 in (
+      (distribs.Continuous('c0', 0., 1.), distribs.Discrete('c1', [0.]), distribs.Continuous('c2', 0.2, 1.)),
+      (distribs.Discrete('c0', [0.05, 0.33, 0.7, 0.999]), distribs.Continuous('c1', 0.1, 1.), distribs.Continuous('c2', 0.1, 1.)),
+      (distribs.Continuous('c0', 0., 1.), distribs.Discrete('c1', [1., 0.37]), distribs.Discrete('c2', [0.9, 0.31])),
+      (distribs.Discrete('c0', [0.1, 0.6]), distribs.Discrete('c1', [0.2, 0.8]), distribs.Discrete('c2', [0.45, 1.])),
+      (distribs.Continuous('c0', 0., 1.), distribs.Continuous('c1', 0., 1.), distribs.Continuous('c2', 0., 1.)),
+  ):
+    groups.append((distribs.Product([distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9),
+                                     c0, c1, c2]), 3))
+  sampler = device_sampler.DeviceSampler(groups, shuffle=False, seed=11)
+  task = tasks.NoReward()
+  rend = {'image': renderer_lib.PILRenderer(image_size=(64, 64), anti_aliasing=1,
+                                            color_to_rgb=renderer_lib.color_maps.hsv_to_rgb)}
+  return sampler, task, rend
+
+
+def _holdouts():
+  """SetMinus rejection in the style of cobra/goal_finding_new_position.py and examples/goal_finding_clustering.py."""
+  position = distribs.SetMinus(
+      distribs.Product((distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9))),
+      distribs.Product((distribs.Continuous('x', 0.5, 0.9), distribs.Continuous('y', 0.5, 0.9))))
+  scale = distribs.SetMinus(distribs.Continuous('scale', 0.05, 0.15), distribs.Continuous('scale', 0.08, 0.12))
+  target = distribs.Product([position, scale, distribs.Discrete('shape', ['square', 'triangle', 'circle']),
+                             distribs.Continuous('c0', 0., 0.4), distribs.Continuous('c1', 0.3, 1.),
+                             distribs.Continuous('c2', 0.9, 1.)])
+  distractor = distribs.Product([distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9),
+                                 distribs.Discrete('shape', ['square', 'triangle', 'circle']),
+                                 distribs.Discrete('scale', [0.13]), distribs.Continuous('c0', 0.5, 0.9),
+                                 distribs.Continuous('c1', 0.3, 1.), distribs.Continuous('c2', 0.9, 1.)])
+  sampler = device_sampler.DeviceSampler([(target, 2), (distractor, 1)], shuffle=False, seed=21)
+  task = tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.4), terminate_distance=0.075)
+  rend = {'image': renderer_lib.PILRenderer(image_size=(64, 64), anti_aliasing=5,
+                                            color_to_rgb=renderer_lib.color_maps.hsv_to_rgb)}
+  return sampler, task, rend
+
+
+CASES = {'cobra_like': _cobra_like, 'mixed_types': _mixed_types, 'hsv_mixed': _hsv_mixed, 'holdouts': _holdouts}
+
+
+def test_philox_known_answers():
+  # Random123 kat_vectors, philox4x32-10
+  assert _sampler_model.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+  f = 0xffffffff
+  assert _sampler_model.philox4x32_10((f, f, f, f), (f, f)) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+  assert (_sampler_model.philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) ==
+          (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_lowering_fills_the_spec(case):
+  sampler, task, rend = CASES[case]()
+  spec = sampler.lower(task, rend)
+  assert spec.n_groups == len(sampler.groups)
+  assert spec.deg_cos[90] == np.cos(np.radians(90)) and spec.deg_sin[270] == np.sin(np.radians(270))
+  for g in range(spec.n_groups):
+    assert spec.groups[g].factor('x').kind == _abi.FACTOR_UNIFORM_F32
+    assert 1 <= spec.groups[g].n_shapes <= _abi.SWB_MAX_CANDIDATES
+  if case == 'cobra_like':
+    assert spec.color_map == 1 and spec.shuffle == 1
+    assert [spec.groups[g].label[0] for g in range(2)] == [1, 0]
+    assert (spec.groups[1].count_min, spec.groups[1].count_max) == (1, 3)
+    assert sampler.max_sprites == 5
+  if case == 'mixed_types':
+    assert spec.color_map == 0
+    assert spec.groups[0].factor('angle').kind == _abi.FACTOR_UNIFORM_INT
+    assert spec.groups[0].factor('c0').kind == _abi.FACTOR_UNIFORM_INT
+    assert spec.groups[1].factor('angle').kind == _abi.FACTOR_DISCRETE and spec.groups[1].factor('angle').n == 4
+    # Clustering labels: group a has c1 in cluster 0; group b has the default c1 = 0, also inside
+    # Continuous('c1', 0, 128) -> first match wins (tasks.py:196-205)
+    assert [spec.groups[g].label[0] for g in range(3)] == [0, 0, 0]
+
+
+def test_setminus_lowers_to_holdout_boxes():
+  sampler, task, rend = _holdouts()
+  spec = sampler.lower(task, rend)
+  grp = spec.groups[0]
+  assert grp.n_holdouts == 2 and spec.groups[1].n_holdouts == 0
+  assert grp.holdouts[0].redraw_mask == 0b11 and grp.holdouts[0].box_mask == 0b11
+  assert (grp.holdouts[0].lo[0], grp.holdouts[0].hi[1]) == (0.5, 0.9)
+  assert grp.holdouts[1].redraw_mask == 0b100 and (grp.holdouts[1].lo[2], grp.holdouts[1].hi[2]) == (0.08, 0.12)
+  # the model never leaves a sprite inside a hold-out box
+  label = lambda f: int(task._filter_distrib.contains(f))
+  got = _sampler_model.sample_pool(spec, 400, 3, 99, rend['image']._color_to_rgb, [label], shapes.SHAPE_NAMES)
+  tx, ty, ts = got['x'][:, :2], got['y'][:, :2], got['scale'][:, :2]
+  assert not ((tx >= 0.5) & (ty >= 0.5)).any() and ((tx >= 0.5) | (ty >= 0.5)).any()
+  assert not ((ts >= 0.08) & (ts < 0.12)).any() and (ts < 0.08).any() and (ts >= 0.12).any()
+  assert ((got['x'][:, 2] >= 0.5) & (got['y'][:, 2] >= 0.5)).any()      # distractors are not held out
+
+
+def test_host_call_draws_valid_sprites():
+  sampler, _, _ = _mixed_types()
+  np.random.seed(0)
+  for _ in range(20):
+    sprites = sampler()
+    assert 3 <= len(sprites) <= 5
+    assert all(isinstance(s, sprite_lib.Sprite) for s in sprites)
+
+
+def test_value_dependent_labels_are_refused():
+  wide = distribs.Product([distribs.Continuous('x', 0., 1.), distribs.Continuous('y', 0., 1.),
+                           distribs.Continuous('c0', 0., 1.)])
+  sampler = device_sampler.DeviceSampler([(wide, 3)])
+  task = tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.4))
+  with pytest.raises(lowering.LoweringError, match='depends on the sampled factors'):
+    sampler.lower(task, {'image': renderer_lib.PILRenderer()})
+
+
+def test_unsupported_distributions_are_refused():
+  mix = distribs.Mixture([distribs.Continuous('x', 0., .5), distribs.Continuous('x', .5, 1.)])
+  with pytest.raises(lowering.LoweringError, match='cannot be sampled on the device'):
+    device_sampler.DeviceSampler([(distribs.Product([mix, distribs.Continuous('y', 0., 1.)]), 1)])
+  f64 = distribs.Product([distribs.Continuous('x', 0., 1., dtype='float64'), distribs.Continuous('y', 0., 1.)])
+  with pytest.raises(lowering.LoweringError):
+    device_sampler.DeviceSampler([(f64, 1)]).lower(tasks.NoReward(), {'image': renderer_lib.PILRenderer()})
+
+
+# ------------------------------------------------------------------------------------- GPU
+def _make_env(case, num_envs=48, episodes_per_env=3):
+  from spriteworld_amd import environment
+  sampler, task, rend = CASES[case]()
+  env = environment.BatchedEnvironment(task=task, action_space=action_spaces.SelectMove(scale=0.25),
+                                       renderers=rend, init_sprites=sampler, max_episode_length=6,
+                                       num_envs=num_envs, episodes_per_env=episodes_per_env)
+  return env, sampler, task, rend
+
+
+def _model_pool(env, sampler, task, rend, seed):
+  spec = env._sampler_spec
+  subs = lowering.subtasks_of(task)
+  label_fns = [(lambda f, sub=sub: lowering._label_of(sub, sprite_lib.Sprite(**f))) for sub in subs]
+  to_rgb = rend['image']._color_to_rgb
+  return _sampler_model.sample_pool(spec, env.num_envs * env._episodes_per_env, env._max_sprites, seed,
+                                    to_rgb, label_fns, shapes.SHAPE_NAMES)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_device_pool_matches_the_model_bit_for_bit(case):
+  env, sampler, task, rend = _make_env(case)
+  for refill in range(2):
+    sampler._draws -= 1
+    seed = sampler.next_seed()   # the key the last swb_sample_pool call used
+    want = _model_pool(env, sampler, task, rend, seed)
+    got = env.engine.get_pool()
+    for name in ('n_sprites', 'x', 'y', 'x_vel', 'y_vel', 'scale', 'cos_a', 'sin_a', 'angle', 'shape', 'rgb',
+                 'color', 'label'):
+      np.testing.assert_array_equal(getattr(got, name), want[name], err_msg='%s (refill %d)' % (name, refill))
+    assert np.array_equal(got.pool_base, np.arange(env.num_envs) * 3) and (got.pool_len == 3).all()
+    env.refill_pool()
+  env.close()
+
+
+@pytest.mark.gpu
+def test_sampled_environment_steps_like_one_built_from_the_same_pool():
+  """Stepping a device-sampled pool == stepping the same pool uploaded from the host (swb_set_pool)."""
+  import torch
+  from spriteworld_amd import engine as engine_lib
+  env, sampler, task, rend = _make_env('cobra_like', num_envs=64, episodes_per_env=2)
+  pool = env.engine.get_pool()
+  twin = engine_lib.Engine(env._cfg, pool)
+  g = torch.Generator(device='cpu').manual_seed(5)
+  env.reset()
+  twin.reset_all()
+  twin.step(env.null_actions(), render=True)
+  assert torch.equal(twin.obs, env.engine.obs)
+  for _ in range(20):
+    act = torch.rand((64, 4), generator=g, dtype=torch.float64)
+    ts = env.step(act.cuda())
+    twin.step(act.cuda())
+    assert torch.equal(twin.obs, ts.observation['image'])
+    np.testing.assert_array_equal(twin.reward.cpu().numpy(), env.engine.reward.cpu().numpy())   # NaN on FIRST
+    assert torch.equal(twin.step_type, env.engine.step_type)
+  env.check()
+  env.close()
+  twin.close()
+
+
+@pytest.mark.gpu
+def test_refill_draws_new_statistically_uniform_episodes():
+  env, sampler, task, rend = _make_env('cobra_like', num_envs=2048, episodes_per_env=4)
+  a = env.engine.get_pool()
+  env.refill_pool()
+  b = env.engine.get_pool()
+  assert not np.array_equal(a.x, b.x)
+  live = np.arange(a.x.shape[1])[None, :] < b.n_sprites[:, None]
+  x = b.x[live]
+  assert 0.1 <= x.min() and x.max() < 0.9 and abs(x.mean() - 0.5) < 0.01 and abs(x.std() - 0.8 / 12 ** 0.5) < 0.01
+  counts = np.bincount(b.n_sprites, minlength=6)[3:6] / len(b.n_sprites)   # 2 targets + randint(1, 4)
+  assert np.all(np.abs(counts - 1 / 3) < 0.03)
+  # shuffle: a target (label 1) lands in every z slot about equally often among 3-sprite episodes
+  three = b.n_sprites == 3
+  first = b.label[three, 0, 0].mean()
+  assert abs(first - 2 / 3) < 0.05
+  shapes_used = np.bincount(b.shape[live], minlength=shapes.shape_index('circle') + 1)
+  assert (shapes_used > 0).sum() == 3
+  env.close()
+
+
+# ------------------------------------------------------------- statistical parity with the reference
+def test_model_matches_the_reference_generators_statistically():
+  """The Philox draw scheme (restated in _sampler_model, bit-equal to the device) and the reference's
+  own MT19937-driven generators produce the same distribution of episodes."""
+  from oracle import ref_harness
+  if not ref_harness.reference_available():
+    pytest.skip('reference tree not present')
+  from scipy import stats
+  ref_harness.load_reference()
+  from spriteworld import factor_distributions as rd
+  from spriteworld import sprite_generators as rg
+  from spriteworld import renderers as rr
+  from spriteworld import tasks as rt
+  common = [rd.Continuous('x', 0.1, 0.9), rd.Continuous('y', 0.1, 0.9),
+            rd.Discrete('shape', ['square', 'triangle', 'circle']), rd.Discrete('scale', [0.13]),
+            rd.Continuous('c1', 0.3, 1.), rd.Continuous('c2', 0.9, 1.)]
+  target = rd.Product(common + [rd.Continuous('c0', 0., 0.4)])
+  distractor = rd.Product(common + [rd.Continuous('c0', 0.5, 0.9)])
+  task = rt.FindGoalPosition(filter_distrib=rd.Continuous('c0', 0., 0.4), terminate_distance=0.1)
+  rend = {'image': rr.PILRenderer(image_size=(64, 64), anti_aliasing=5, color_to_rgb=rr.color_maps.hsv_to_rgb)}
+  # the reference's classes lower unchanged (duck-typed)
+  sampler = device_sampler.DeviceSampler([(target, 2), (distractor, (1, 4))], shuffle=True, seed=1)
+  spec = sampler.lower(task, rend)
+  P = 3000
+  label_fn = lambda f: int(task._filter_distrib.contains(f))
+  got = _sampler_model.sample_pool(spec, P, 5, sampler.next_seed(), rr.color_maps.hsv_to_rgb, [label_fn],
+                                   shapes.SHAPE_NAMES)
+  gen = rg.shuffle(rg.chain_generators(rg.generate_sprites(target, num_sprites=2),
+                                       rg.generate_sprites(distractor, num_sprites=lambda: np.random.randint(1, 4))))
+  np.random.seed(123)
+  ref_eps = [gen() for _ in range(P)]
+  ref_n = np.array([len(e) for e in ref_eps])
+  assert stats.chisquare(np.bincount(got['n_sprites'], minlength=6)[3:], np.bincount(ref_n, minlength=6)[3:]).pvalue > 1e-3
+  live = np.arange(5)[None, :] < got['n_sprites'][:, None]
+  for key, col in (('x', got['x']), ('y', got['y']), ('c0', got['color'][..., 0]), ('c1', got['color'][..., 1])):
+    ref_vals = np.array([float(s.factors[key]) for e in ref_eps for s in e])
+    assert stats.ks_2samp(col[live], ref_vals).pvalue > 1e-3, key
+  for ch in range(3):
+    ref_rgb = np.array([rr.color_maps.hsv_to_rgb(s.color)[ch] for e in ref_eps for s in e], dtype=np.float64)
+    assert stats.ks_2samp(got['rgb'][..., ch][live].astype(np.float64), ref_rgb).pvalue > 1e-3
+  # z-order: P(back-most sprite is a target)
+  ref_first = np.mean([e[0].c0 < 0.4 for e in ref_eps])
+  assert abs(got['label'][:, 0, 0].mean() - ref_first) < 0.04
+  ref_shapes = np.bincount([shapes.shape_index(s.shape) for e in ref_eps for s in e], minlength=len(shapes.SHAPE_NAMES))
+  got_shapes = np.bincount(got['shape'][live], minlength=len(shapes.SHAPE_NAMES))
+  nz = ref_shapes > 0
+  assert (got_shapes > 0).tolist() == nz.tolist()
+  assert stats.chisquare(got_shapes[nz] * (ref_shapes[nz].sum() / got_shapes[nz].sum()), ref_shapes[nz]).pvalue > 1e-3
