@@ -38,13 +38,17 @@ def load_reference():
         return lambda x: np.asarray(x).astype(dtype)
 
     np.cast = _Cast()
+  # Never write __pycache__ into the reference: this process and every child it spawns.
+  sys.dont_write_bytecode = True
+  os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+  # Appended, not prepended: the reference tree also holds a top-level `tests` package that must
+  # not shadow this repository's.
   try:
     import dm_env  # noqa: F401  (a real dm_env wins if one is ever installed)
   except ImportError:
-    sys.path.insert(0, _COMPAT)
+    sys.path.append(_COMPAT)
   if REFERENCE_ROOT not in sys.path:
-    sys.path.insert(0, REFERENCE_ROOT)
-  sys.dont_write_bytecode = True  # never write __pycache__ into the reference
+    sys.path.append(REFERENCE_ROOT)
   import spriteworld
   from spriteworld import environment, sprite, tasks, action_spaces  # noqa: F401
   from spriteworld import renderers, factor_distributions  # noqa: F401
