@@ -1,0 +1,181 @@
+"""Gym-style surface over the engine (reference gym_wrapper.py:26-135).
+
+`GymWrapper(env)` wraps the N = 1 `environment.Environment` exactly like the reference wrapper:
+`step -> (obs, reward or 0, done, {'discount': ...})`, boolean observations as float32, `render()`
+returning the last image.  `BatchedGymWrapper(env)` is the same contract over a
+`BatchedEnvironment`: every value is a device tensor with a leading N axis and the rewards /
+discounts of FIRST steps (None in the reference) are 0 / NaN.
+
+`gym` is optional: without it the spaces are the small stand-ins below (same attributes).
+"""
+import numpy as np
+import torch
+
+from spriteworld_amd import dm_env_compat as dm_env
+
+specs = dm_env.specs
+
+try:  # pragma: no cover - gym is not installed in the build image
+  from gym import spaces
+except ImportError:
+
+  class _Space(object):
+
+    def __repr__(self):
+      return '%s(%s)' % (type(self).__name__, ', '.join('%s=%r' % kv for kv in sorted(vars(self).items())))
+
+  class _Spaces(object):
+
+    class Box(_Space):
+
+      def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape or ()), np.dtype(dtype)
+
+      def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    class Discrete(_Space):
+
+      def __init__(self, n):
+        self.n = int(n)
+
+      def contains(self, x):
+        return 0 <= int(x) < self.n
+
+    class Tuple(_Space):
+
+      def __init__(self, spaces_):
+        self.spaces = tuple(spaces_)
+
+    class Dict(_Space):
+
+      def __init__(self, spaces_):
+        self.spaces = dict(spaces_)
+
+  spaces = _Spaces
+
+
+def _spec_to_space(spec):
+  """dm_env.specs -> gym.spaces (gym_wrapper.py:26-39)."""
+  if isinstance(spec, list):
+    return spaces.Tuple([_spec_to_space(s) for s in spec])
+  if isinstance(spec, specs.DiscreteArray):
+    return spaces.Discrete(spec.num_values)
+  if isinstance(spec, specs.BoundedArray):
+    return spaces.Box(np.asarray(spec.minimum).item(), np.asarray(spec.maximum).item(), shape=spec.shape,
+                      dtype=spec.dtype)
+  raise ValueError('Unknown type for specs: {}'.format(spec))
+
+
+class GymWrapper(object):
+  """Gym interface of a single environment; observations keyed like the `renderers` dict."""
+  metadata = {'render.modes': ['rgb_array']}
+
+  def __init__(self, env):
+    self._env = env
+    self._last_render = None
+    self._action_space = None
+    self._observation_space = None
+    self._env.reset()
+
+  def __getattr__(self, name):
+    return getattr(self._env, name)
+
+  @property
+  def observation_space(self):
+    if self._observation_space is None:
+      self._observation_space = spaces.Dict({
+          key: spaces.Box(-np.inf, np.inf, value.shape, dtype=value.dtype)
+          for key, value in self._env.observation_spec().items()})
+    return self._observation_space
+
+  @property
+  def action_space(self):
+    if self._action_space is None:
+      self._action_space = _spec_to_space(self._env.action_spec())
+    return self._action_space
+
+  def _process_obs(self, obs):
+    for k, v in obs.items():
+      obs[k] = np.asarray(v)
+      if obs[k].dtype == np.bool_:
+        obs[k] = obs[k].astype(np.float32)
+      if k == 'image':
+        self._last_render = obs[k]
+    return obs
+
+  def step(self, action):
+    time_step = self._env.step(action)
+    obs = self._process_obs(time_step.observation)
+    reward = time_step.reward or 0
+    done = time_step.last()
+    return obs, reward, done, {'discount': time_step.discount}
+
+  def reset(self):
+    return self._process_obs(self._env.reset().observation)
+
+  def render(self, mode='rgb_array'):
+    del mode
+    return self._last_render
+
+  def close(self):
+    pass
+
+
+class BatchedGymWrapper(object):
+  """The same contract for N environments: tensors with a leading N axis, auto-reset included.
+
+  An environment whose step returned done=True restarts on the next `step` (its action is ignored,
+  like the reference's Environment, environment.py:90-91) and reports reward 0 on that FIRST step.
+  """
+  metadata = {'render.modes': ['rgb_array']}
+
+  def __init__(self, env):
+    self._env = env
+    self._last_render = None
+    self._action_space = None
+    self._observation_space = None
+    self._env.reset()
+
+  def __getattr__(self, name):
+    return getattr(self._env, name)
+
+  @property
+  def observation_space(self):
+    if self._observation_space is None:
+      n = self._env.num_envs
+      self._observation_space = spaces.Dict({
+          key: spaces.Box(-np.inf, np.inf, (n,) + tuple(value.shape), dtype=value.dtype)
+          for key, value in self._env.observation_spec().items()})
+    return self._observation_space
+
+  @property
+  def action_space(self):
+    if self._action_space is None:
+      self._action_space = _spec_to_space(self._env.action_spec())
+    return self._action_space
+
+  def _process_obs(self, obs):
+    out = {}
+    for k, v in obs.items():
+      out[k] = v.to(torch.float32) if v.dtype == torch.bool else v
+      if k == 'image':
+        self._last_render = out[k]
+    return out
+
+  def step(self, actions):
+    ts = self._env.step(actions)
+    reward = torch.nan_to_num(ts.reward, nan=0.0)           # `reward or 0`
+    done = ts.step_type == int(dm_env.StepType.LAST)
+    return self._process_obs(ts.observation), reward, done, {'discount': ts.discount}
+
+  def reset(self):
+    return self._process_obs(self._env.reset().observation)
+
+  def render(self, mode='rgb_array'):
+    del mode
+    return self._last_render
+
+  def close(self):
+    self._env.close()

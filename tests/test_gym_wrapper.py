@@ -1,0 +1,92 @@
+"""Gym-style wrappers (reference gym_wrapper.py:26-135)."""
+import numpy as np
+import pytest
+
+from spriteworld_amd import action_spaces, gym_wrapper
+from spriteworld_amd import dm_env_compat as dm_env
+
+from tests import test_host_api
+
+
+class _ScriptedEnv(object):
+  """dm_env-style stub: FIRST, MID (reward 0.5), LAST (reward 0.0)."""
+
+  def __init__(self):
+    self._k = 0
+    self._space = action_spaces.SelectMove(scale=0.25)
+
+  def action_spec(self):
+    return self._space.action_spec()
+
+  def observation_spec(self):
+    return {'image': dm_env.specs.Array((4, 4, 3), np.uint8), 'success': dm_env.specs.Array((), np.bool_)}
+
+  def _obs(self):
+    return {'image': np.full((4, 4, 3), self._k, np.uint8), 'success': self._k == 2}
+
+  def reset(self):
+    self._k = 0
+    return dm_env.restart(self._obs())
+
+  def step(self, action):
+    self._k += 1
+    if self._k == 1:
+      return dm_env.transition(0.5, self._obs())
+    return dm_env.termination(0.0, self._obs())
+
+
+def test_gym_wrapper_follows_the_reference_contract():
+  env = gym_wrapper.GymWrapper(_ScriptedEnv())
+  assert env.action_space.shape == (4,) and env.action_space.low == 0.0 and env.action_space.high == 1.0
+  assert sorted(env.observation_space.spaces) == ['image', 'success']
+  obs = env.reset()
+  assert obs['success'].dtype == np.float32 and obs['success'] == 0.0 and env.render() is obs['image']
+  obs, reward, done, info = env.step(np.zeros(4))
+  assert (reward, done, info['discount']) == (0.5, False, 1.0)
+  obs, reward, done, info = env.step(np.zeros(4))
+  assert reward == 0 and done and info['discount'] == 0.0 and obs['success'] == 1.0
+  assert env.render()[0, 0, 0] == 2
+  assert env.observation_spec is not None   # __getattr__ passthrough
+
+
+def test_spec_to_space_kinds():
+  emb = action_spaces.Embodied(step_size=0.05).action_spec()
+  space = gym_wrapper._spec_to_space(emb)
+  assert [type(s).__name__ for s in space.spaces] == ['Discrete', 'Discrete'] and [s.n for s in space.spaces] == [2, 4]
+  with pytest.raises(ValueError):
+    gym_wrapper._spec_to_space(dm_env.specs.Array((), np.float32))
+
+
+@pytest.mark.gpu
+def test_gym_wrappers_on_the_engine():
+  import torch
+  from spriteworld_amd import environment
+  np.random.seed(3)
+  config = test_host_api._cobra_like_config()
+  config['renderers']['success'] = __import__('spriteworld_amd.renderers', fromlist=['Success']).Success()
+  single = gym_wrapper.GymWrapper(environment.Environment(**config))
+  obs = single.reset()
+  assert obs['image'].shape == (64, 64, 3) and obs['image'].dtype == np.uint8 and obs['success'].dtype == np.float32
+  steps = 0
+  done = False
+  while not done:
+    obs, reward, done, info = single.step(single._env.action_space.sample())
+    assert isinstance(reward, float) and info['discount'] in (0.0, 1.0)
+    steps += 1
+  assert steps <= 20 and single.render() is obs['image']
+
+  np.random.seed(3)
+  batched = gym_wrapper.BatchedGymWrapper(environment.BatchedEnvironment(num_envs=32, **config))
+  obs = batched.reset()
+  assert obs['image'].shape == (32, 64, 64, 3) and obs['success'].dtype == torch.float32
+  dones = torch.zeros(32, dtype=torch.bool, device='cuda')
+  seen_done = 0
+  for _ in range(25):
+    prev_done = dones
+    obs, reward, dones, info = batched.step(batched.sample_actions())
+    assert reward.shape == (32,) and not torch.isnan(reward).any()
+    assert (reward[prev_done] == 0).all()                      # FIRST steps after an auto-reset
+    assert torch.isnan(info['discount'][prev_done]).all()
+    seen_done += int(dones.sum())
+  assert seen_done >= 32            # max_episode_length = 20 ends every episode within 25 steps
+  batched.close()
