@@ -240,9 +240,11 @@ int swb_upload_resample(swb_handle h, int32_t axis /*0=horizontal,1=vertical*/, 
 int swb_set_pool(swb_handle h, const swb_pool* pool);
 
 /* Fills a pool of `n_entries` episodes on the device from `spec` (no host sampling, no upload) and
- * marks every environment "reset on next step", like swb_set_pool.  pool_base/pool_len: i32[N]. */
+ * marks every environment "reset on next step", like swb_set_pool.  pool_base/pool_len: i32[N].
+ * Entry e draws from the Philox stream (seed, first_entry + e): shards of one job pass their global
+ * offset and get the episodes a single process would have drawn for the same entries. */
 int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, const int32_t* pool_base_host,
-                    const int32_t* pool_len_host, uint64_t seed, void* stream);
+                    const int32_t* pool_len_host, uint64_t seed, uint64_t first_entry, void* stream);
 
 /* Copies the device pool into caller-allocated HOST arrays laid out like swb_set_pool's input
  * (pool->n_entries must equal the device pool's; angle/color may be NULL).  Synchronous. */

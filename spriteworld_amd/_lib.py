@@ -48,7 +48,7 @@ def load():
                                       C.c_void_p]
   lib.swb_set_pool.argtypes = [C.c_void_p, C.POINTER(_abi.SwbPool)]
   lib.swb_sample_pool.argtypes = [C.c_void_p, C.POINTER(_abi.SwbSampler), C.c_int32, C.c_void_p, C.c_void_p,
-                                  C.c_uint64, C.c_void_p]
+                                  C.c_uint64, C.c_uint64, C.c_void_p]
   lib.swb_get_pool.argtypes = [C.c_void_p, C.POINTER(_abi.SwbPool)]
   lib.swb_reset_all.argtypes = [C.c_void_p, C.c_void_p]
   lib.swb_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.SwbOutputs), C.c_void_p]

@@ -374,7 +374,7 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
 }
 
 int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, const int32_t* pool_base_host,
-                    const int32_t* pool_len_host, uint64_t seed, void* stream) {
+                    const int32_t* pool_len_host, uint64_t seed, uint64_t first_entry, void* stream) {
   if (!h || !spec || !pool_base_host || !pool_len_host) return fail(SWB_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(h->device));
   const int P = n_entries, S = h->p.S, T = h->p.n_tasks, N = h->p.N;
@@ -435,7 +435,7 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
   p.p_scale = h->d_p_scale; p.p_ca = h->d_p_ca; p.p_sa = h->d_p_sa; p.p_shape = h->d_p_shape; p.p_rgb = h->d_p_rgb;
   p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
   p.p_angle = h->d_p_angle; p.p_color = h->d_p_color;
-  swb_sampler_args a{h->d_sampler, P, S, T, seed, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale,
+  swb_sampler_args a{h->d_sampler, P, S, T, seed, first_entry, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale,
                      h->d_p_ca, h->d_p_sa, h->d_p_angle, h->d_p_color, h->d_p_shape, h->d_p_rgb, h->d_p_label};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(swb_sample_pool_kernel, dim3((P + 255) / 256), dim3(256), 0, st, a);

@@ -18,6 +18,23 @@ def shard_range(num_envs, rank, world):
   return rank * num_envs // world, (rank + 1) * num_envs // world
 
 
+def sharded_environment(total_envs, rank=None, world=None, **config):
+  """This rank's BatchedEnvironment of a `total_envs` job (one process per GPU, LOCAL_RANK device).
+
+  `config` is what BatchedEnvironment takes.  The shard knows its global offset, so device-side
+  reset sampling (device_sampler.DeviceSampler) draws the episodes a single process would have
+  drawn for the same environments."""
+  import os
+  from spriteworld_amd import environment
+  if rank is None:
+    rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get('RANK', 0))
+  if world is None:
+    world = dist.get_world_size() if dist.is_initialized() else int(os.environ.get('WORLD_SIZE', 1))
+  begin, end = shard_range(total_envs, rank, world)
+  config.setdefault('device', int(os.environ.get('LOCAL_RANK', 0)))
+  return environment.BatchedEnvironment(num_envs=end - begin, global_env_offset=begin, **config)
+
+
 def all_gather_observations(obs_shard, out=None):
   """Stacks every rank's u8 [n, H, W, 3] shard into [world*n, H, W, 3] on each rank."""
   world = dist.get_world_size()

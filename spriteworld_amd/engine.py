@@ -86,13 +86,14 @@ class Engine(object):
     cpool = pool.as_struct()
     _lib.check(self.lib.swb_set_pool(self._h, C.byref(cpool)))
 
-  def sample_pool(self, spec, n_entries, pool_base, pool_len, seed):
+  def sample_pool(self, spec, n_entries, pool_base, pool_len, seed, first_entry=0):
     """Draws `n_entries` episodes on the device from an _abi.SwbSampler (swb_sample_pool)."""
     base = np.ascontiguousarray(pool_base, dtype=np.int32)
     length = np.ascontiguousarray(pool_len, dtype=np.int32)
     assert base.shape == (self.N,) and length.shape == (self.N,)
     _lib.check(self.lib.swb_sample_pool(self._h, C.byref(spec), int(n_entries), _ptr(base), _ptr(length),
-                                        C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), self._stream()))
+                                        C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_uint64(int(first_entry)),
+                                        self._stream()))
     self.pool = None
     self._pool_entries = int(n_entries)
 

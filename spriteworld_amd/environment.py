@@ -44,7 +44,8 @@ class BatchedEnvironment(object):
 
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, num_envs=1, episodes_per_env=8,
-               max_sprites=None, device=0, check_errors=32, action_dtype=np.float64):
+               max_sprites=None, device=0, check_errors=32, action_dtype=np.float64,
+               global_env_offset=0):
     self._task = task
     self._action_space = action_space
     self._renderers = renderers
@@ -54,6 +55,9 @@ class BatchedEnvironment(object):
     self._metadata = metadata
     self._num_envs = int(num_envs)
     self._episodes_per_env = int(episodes_per_env)
+    # index of this shard's first environment in the whole job (distributed.shard_range): device-side
+    # reset sampling draws entry streams by global index, so shards never repeat each other's episodes
+    self._global_env_offset = int(global_env_offset)
     # Per-environment error flags (conditions that make the reference raise) are read back every
     # `check_errors` steps (True/1: every step, which costs a device sync per step; 0/False: never;
     # `check()` can be called at any time).
@@ -105,7 +109,8 @@ class BatchedEnvironment(object):
       k = self._episodes_per_env
       base = np.arange(self._num_envs, dtype=np.int32) * k
       self._engine.sample_pool(self._sampler_spec, self._num_envs * k, base,
-                               np.full(self._num_envs, k, np.int32), self._sampler.next_seed())
+                               np.full(self._num_envs, k, np.int32), self._sampler.next_seed(),
+                               first_entry=self._global_env_offset * k)
       return
     episodes = self._draw_episodes()
     pool = lowering.lower_episodes(episodes, self._task, self._renderers,

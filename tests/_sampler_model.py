@@ -30,11 +30,11 @@ class Stream(object):
 
   def __init__(self, seed, entry):
     self.key = (seed & M32, (seed >> 32) & M32)
-    self.entry, self.block, self.buf = entry, 0, []
+    self.entry, self.entry_hi, self.block, self.buf = entry & M32, entry >> 32, 0, []
 
   def u32(self):
     if not self.buf:
-      self.buf = list(philox4x32_10((self.entry, self.block, 0, 0), self.key))
+      self.buf = list(philox4x32_10((self.entry, self.block, self.entry_hi, 0), self.key))
       self.block += 1
     return self.buf.pop(0)
 
@@ -52,7 +52,7 @@ def _draw(rng, fac, np_dtype=None):
   return np.float32(val)
 
 
-def sample_pool(spec, n_entries, max_sprites, seed, to_rgb, label_fns, shape_names):
+def sample_pool(spec, n_entries, max_sprites, seed, to_rgb, label_fns, shape_names, first_entry=0):
   """Returns a dict of arrays laid out like lowering.Pool."""
   P, S, T = n_entries, max_sprites, len(label_fns)
   out = dict(n_sprites=np.zeros(P, np.int32), x=np.zeros((P, S)), y=np.zeros((P, S)), x_vel=np.zeros((P, S)),
@@ -60,7 +60,7 @@ def sample_pool(spec, n_entries, max_sprites, seed, to_rgb, label_fns, shape_nam
              angle=np.zeros((P, S)), shape=np.zeros((P, S), np.int32), rgb=np.zeros((P, S, 4), np.uint8),
              color=np.zeros((P, S, 3)), label=np.zeros((P, T, S), np.int8))
   for e in range(P):
-    rng = Stream(seed, e)
+    rng = Stream(seed, first_entry + e)
     counts, n = [], 0
     for g in range(spec.n_groups):
       grp = spec.groups[g]

@@ -207,6 +207,25 @@ def test_device_pool_matches_the_model_bit_for_bit(case):
 
 
 @pytest.mark.gpu
+def test_shards_draw_the_episodes_of_the_whole_job():
+  """global_env_offset: two 24-env shards hold the same pool as one 48-env process (no repeated streams)."""
+  from spriteworld_amd import environment
+  whole, sampler, task, rend = _make_env('cobra_like', num_envs=48)
+  want = whole.engine.get_pool()
+  for rank in range(2):
+    s2, _, _ = CASES['cobra_like']()
+    shard = environment.BatchedEnvironment(task=task, action_space=action_spaces.SelectMove(scale=0.25),
+                                           renderers=rend, init_sprites=s2, max_episode_length=6, num_envs=24,
+                                           episodes_per_env=3, global_env_offset=24 * rank)
+    got = shard.engine.get_pool()
+    sl = slice(72 * rank, 72 * (rank + 1))
+    for name in ('n_sprites', 'x', 'y', 'shape', 'rgb', 'label'):
+      np.testing.assert_array_equal(getattr(got, name), getattr(want, name)[sl], err_msg=name)
+    shard.close()
+  whole.close()
+
+
+@pytest.mark.gpu
 def test_sampled_environment_steps_like_one_built_from_the_same_pool():
   """Stepping a device-sampled pool == stepping the same pool uploaded from the host (swb_set_pool)."""
   import torch
