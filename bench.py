@@ -73,6 +73,7 @@ def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
   torch.cuda.synchronize(eng.device)
   if barrier:
     barrier()
+    torch.cuda.synchronize(eng.device)
   elapsed = time.perf_counter() - t0
   kernel_ms, launches = eng.step_time_ms()
   eng.timing(False)
