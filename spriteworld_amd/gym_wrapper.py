@@ -35,6 +35,12 @@ except ImportError:
         x = np.asarray(x)
         return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
 
+      def sample(self):
+        return np.random.uniform(self.low, self.high, size=self.shape).astype(self.dtype)
+
+      def __eq__(self, other):
+        return type(other) is type(self) and vars(other) == vars(self)
+
     class Discrete(_Space):
 
       def __init__(self, n):
@@ -43,15 +49,33 @@ except ImportError:
       def contains(self, x):
         return 0 <= int(x) < self.n
 
+      def sample(self):
+        return int(np.random.randint(self.n))
+
+      def __eq__(self, other):
+        return type(other) is type(self) and other.n == self.n
+
     class Tuple(_Space):
 
       def __init__(self, spaces_):
         self.spaces = tuple(spaces_)
 
+      def sample(self):
+        return tuple(s.sample() for s in self.spaces)
+
+      def __eq__(self, other):
+        return type(other) is type(self) and other.spaces == self.spaces
+
     class Dict(_Space):
 
       def __init__(self, spaces_):
         self.spaces = dict(spaces_)
+
+      def sample(self):
+        return {k: s.sample() for k, s in self.spaces.items()}
+
+      def __eq__(self, other):
+        return type(other) is type(self) and other.spaces == self.spaces
 
   spaces = _Spaces
 

@@ -90,3 +90,32 @@ def test_gym_wrappers_on_the_engine():
     seen_done += int(dones.sum())
   assert seen_done >= 32            # max_episode_length = 20 ends every episode within 25 steps
   batched.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('embodied', [False, True])
+def test_reference_gym_wrapper_episode_pattern(embodied):
+  """tests/gym_wrapper_test.py:38-111: spaces, then 3 episodes of max_episode_length = 5 with the
+  done flag only on the last step and a not-done (auto-reset) step after it."""
+  from spriteworld_amd import environment, renderers, tasks
+  from spriteworld_amd.sprite import Sprite
+  spaces = gym_wrapper.spaces
+  space = action_spaces.Embodied() if embodied else action_spaces.SelectMove()
+  env = gym_wrapper.GymWrapper(environment.Environment(
+      tasks.NoReward(), space, {'image': renderers.PILRenderer(image_size=(64, 64))},
+      lambda: [Sprite(c0=255)], max_episode_length=5))
+  assert env.observation_space == spaces.Dict({'image': spaces.Box(-np.inf, np.inf, shape=(64, 64, 3), dtype=np.uint8)})
+  if embodied:
+    assert env.action_space == spaces.Tuple([spaces.Discrete(2), spaces.Discrete(4)])
+  else:
+    assert env.action_space == spaces.Box(0., 1., shape=(4,), dtype=np.float32)
+  np.random.seed(0)
+  for _ in range(3):
+    env.reset()
+    for _ in range(4):
+      obs, reward, done, _ = env.step(env.action_space.sample())
+      assert obs['image'].dtype == np.uint8 and not done and reward == 0.
+    _, _, done, _ = env.step(env.action_space.sample())
+    assert done
+    _, _, done, _ = env.step(env.action_space.sample())
+    assert not done
