@@ -42,6 +42,16 @@ CASES = [
     # float32 action arrays (the dtype action_spec() declares), with a motion cost
     ('cobra_clustering_f32_actions', 'spriteworld.configs.cobra.clustering', 'test', 12, 200, 18, 'float32', 0.6),
     ('cobra_sorting_f32_actions', 'spriteworld.configs.cobra.sorting', 'test', 12, 160, 19, 'float32', 0.25),
+    # the remaining config x mode combinations (tests/configs/configs_test.py grid)
+    ('cobra_new_shape_train', 'spriteworld.configs.cobra.goal_finding_new_shape', 'train', 12, 120, 20),
+    ('cobra_new_shape_test', 'spriteworld.configs.cobra.goal_finding_new_shape', 'test', 12, 120, 21),
+    ('cobra_more_targets_train', 'spriteworld.configs.cobra.goal_finding_more_targets', 'train', 12, 120, 22),
+    ('cobra_more_targets_test', 'spriteworld.configs.cobra.goal_finding_more_targets', 'test', 12, 120, 23),
+    ('cobra_new_position_train', 'spriteworld.configs.cobra.goal_finding_new_position', 'train', 12, 120, 24),
+    ('cobra_more_distractors_test', 'spriteworld.configs.cobra.goal_finding_more_distractors', 'test', 12, 120, 25),
+    ('cobra_exploration_test', 'spriteworld.configs.cobra.exploration', 'test', 12, 120, 26),
+    ('examples_embodied_test', 'spriteworld.configs.examples.goal_finding_embodied', 'test', 8, 120, 27),
+    ('examples_goal_clustering_test', 'spriteworld.configs.examples.goal_finding_clustering', 'test', 8, 120, 28),
 ]
 FULL_FRAMES = 6
 
@@ -120,8 +130,10 @@ def make(name, module, mode, n_eps, n_steps, seed, action_dtype='float64', motio
 
 def main():
   ref_harness.load_reference()
+  only = set(sys.argv[1:])          # optional: names of the cases to (re)generate
   for case in CASES:
-    make(*case)
+    if not only or case[0] in only:
+      make(*case)
   # shape tables
   from spriteworld import constants
   import json

@@ -11,17 +11,19 @@ from oracle import ref_harness
 pytestmark = pytest.mark.skipif(not ref_harness.reference_available(),
                                 reason='reference tree not present')
 
-CONFIGS = [
-    ('spriteworld.configs.cobra.goal_finding_new_position', 'train'),
-    ('spriteworld.configs.cobra.goal_finding_new_shape', 'test'),
-    ('spriteworld.configs.cobra.goal_finding_more_distractors', 'test'),
-    ('spriteworld.configs.cobra.goal_finding_more_targets', 'train'),
-    ('spriteworld.configs.cobra.clustering', 'test'),
-    ('spriteworld.configs.cobra.sorting', 'test'),
-    ('spriteworld.configs.cobra.exploration', 'train'),
-    ('spriteworld.configs.examples.goal_finding_embodied', 'test'),
-    ('spriteworld.configs.examples.goal_finding_clustering', 'test'),
+_MODULES = [
+    'spriteworld.configs.cobra.goal_finding_new_position',
+    'spriteworld.configs.cobra.goal_finding_new_shape',
+    'spriteworld.configs.cobra.goal_finding_more_distractors',
+    'spriteworld.configs.cobra.goal_finding_more_targets',
+    'spriteworld.configs.cobra.clustering',
+    'spriteworld.configs.cobra.sorting',
+    'spriteworld.configs.cobra.exploration',
+    'spriteworld.configs.examples.goal_finding_embodied',
+    'spriteworld.configs.examples.goal_finding_clustering',
 ]
+# every shipped config in both modes (tests/configs/configs_test.py:33-58 runs the same grid)
+CONFIGS = [(m, mode) for m in _MODULES for mode in ('train', 'test')]
 
 
 def _bits(v):
