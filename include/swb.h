@@ -187,11 +187,22 @@ typedef struct swb_sprite_group {
   double cos_a[SWB_MAX_CANDIDATES], sin_a[SWB_MAX_CANDIDATES]; /* of angle.cand (radians)  */
   int8_t label[SWB_MAX_TASKS];                                 /* task label of the group  */
 } swb_sprite_group;
+/* sprite_generators.sample_generator (sprite_generators.py:73-98, uniform p): each episode uses ONE
+ * alternative, a list of groups (indices into swb_sampler.groups) generated in that order. */
+#define SWB_MAX_ALTERNATIVES 16
+typedef struct swb_alternative {
+  int32_t n;
+  int32_t group[SWB_MAX_GROUPS];
+} swb_alternative;
 typedef struct swb_sampler {
   int32_t n_groups;
-  int32_t shuffle;          /* sprite_generators.shuffle                                   */
+  int32_t shuffle;          /* sprite_generators.shuffle over the sprites of the first `shuffle`
+                             * generated groups (0: none, >= the number generated: all); later
+                             * groups keep their place, e.g. the agent body of
+                             * examples/goal_finding_embodied.py:88-93                        */
   int32_t color_map;        /* 0: (c0,c1,c2) are RGB ints; 1: renderers.color_maps.hsv_to_rgb */
-  int32_t reserved;
+  int32_t n_alternatives;   /* 0: every group, in order; else one of alternatives[] per episode */
+  swb_alternative alternatives[SWB_MAX_ALTERNATIVES];
   double deg_cos[360], deg_sin[360]; /* math.cos/sin(math.radians(d)) for integer degrees  */
   swb_sprite_group groups[SWB_MAX_GROUPS];
 } swb_sampler;
@@ -245,6 +256,12 @@ int swb_set_pool(swb_handle h, const swb_pool* pool);
  * offset and get the episodes a single process would have drawn for the same entries. */
 int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, const int32_t* pool_base_host,
                     const int32_t* pool_len_host, uint64_t seed, uint64_t first_entry, void* stream);
+
+/* Redraws the pool with the spec and layout of the last swb_sample_pool and a new seed, WITHOUT
+ * resetting anything: entries an environment is currently playing are left untouched, so a long
+ * run calls this every few episodes and never sees an episode twice.  Asynchronous on `stream`
+ * (the same stream as swb_step, or ordered with it). */
+int swb_resample_pool(swb_handle h, uint64_t seed, uint64_t first_entry, void* stream);
 
 /* Copies the device pool into caller-allocated HOST arrays laid out like swb_set_pool's input
  * (pool->n_entries must equal the device pool's; angle/color may be NULL).  Synchronous. */

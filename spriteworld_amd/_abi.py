@@ -150,12 +150,23 @@ class SwbSpriteGroup(C.Structure):
   ]
 
 
+SWB_MAX_ALTERNATIVES = 16
+
+
+class SwbAlternative(C.Structure):
+  _fields_ = [
+      ('n', C.c_int32),
+      ('group', C.c_int32 * SWB_MAX_GROUPS),
+  ]
+
+
 class SwbSampler(C.Structure):
   _fields_ = [
       ('n_groups', C.c_int32),
       ('shuffle', C.c_int32),
       ('color_map', C.c_int32),
-      ('reserved', C.c_int32),
+      ('n_alternatives', C.c_int32),
+      ('alternatives', SwbAlternative * SWB_MAX_ALTERNATIVES),
       ('deg_cos', C.c_double * 360),
       ('deg_sin', C.c_double * 360),
       ('groups', SwbSpriteGroup * SWB_MAX_GROUPS),

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libswb.so')
 # Every symbol include/swb.h declares (tests check the library exports them all).
 EXPORTS = (
     'swb_last_error', 'swb_version', 'swb_create', 'swb_destroy', 'swb_upload_shapes',
-    'swb_upload_resample', 'swb_set_pool', 'swb_sample_pool', 'swb_get_pool', 'swb_reset_all', 'swb_step', 'swb_render', 'swb_factors',
+    'swb_upload_resample', 'swb_set_pool', 'swb_sample_pool', 'swb_resample_pool', 'swb_get_pool', 'swb_reset_all', 'swb_step', 'swb_render', 'swb_factors',
     'swb_get_state', 'swb_set_positions', 'swb_timing_enable', 'swb_step_time_ms',
 )
 
@@ -49,6 +49,7 @@ def load():
   lib.swb_set_pool.argtypes = [C.c_void_p, C.POINTER(_abi.SwbPool)]
   lib.swb_sample_pool.argtypes = [C.c_void_p, C.POINTER(_abi.SwbSampler), C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_uint64, C.c_uint64, C.c_void_p]
+  lib.swb_resample_pool.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
   lib.swb_get_pool.argtypes = [C.c_void_p, C.POINTER(_abi.SwbPool)]
   lib.swb_reset_all.argtypes = [C.c_void_p, C.c_void_p]
   lib.swb_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.SwbOutputs), C.c_void_p]

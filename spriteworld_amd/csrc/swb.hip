@@ -71,6 +71,7 @@ struct swb_engine {
   double *d_p_angle = nullptr, *d_p_color = nullptr;
   swb_sampler* d_sampler = nullptr;
   int pool_entries = 0;
+  bool pool_sampled = false, pool_uniform = false;   // pool came from swb_sample_pool / env-major fixed-length layout
   double *d_x = nullptr, *d_y = nullptr;
   int32_t *d_nspr = nullptr, *d_entry = nullptr, *d_step_count = nullptr, *d_episode = nullptr;
   uint8_t* d_reset_next = nullptr;
@@ -366,6 +367,7 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
   p.p_scale = h->d_p_scale; p.p_ca = h->d_p_ca; p.p_sa = h->d_p_sa; p.p_shape = h->d_p_shape; p.p_rgb = h->d_p_rgb;
   p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
   h->pool_entries = P;
+  h->pool_sampled = false;
   HIP_TRY(hipMemset(h->d_reset_next, 1, N));      // environment.py:70
   HIP_TRY(hipMemset(h->d_episode, 0, sizeof(int32_t) * N));
   HIP_TRY(hipMemset(h->d_step_count, 0, sizeof(int32_t) * N));
@@ -380,6 +382,15 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
   const int P = n_entries, S = h->p.S, T = h->p.n_tasks, N = h->p.N;
   if (P < 1) return fail(SWB_ERR_INVALID, "pool is empty");
   if (spec->n_groups < 1 || spec->n_groups > SWB_MAX_GROUPS) return fail(SWB_ERR_INVALID, "n_groups must be in [1, %d]", SWB_MAX_GROUPS);
+  if (spec->shuffle < 0) return fail(SWB_ERR_INVALID, "shuffle must be >= 0");
+  if (spec->n_alternatives < 0 || spec->n_alternatives > SWB_MAX_ALTERNATIVES)
+    return fail(SWB_ERR_INVALID, "n_alternatives must be in [0, %d]", SWB_MAX_ALTERNATIVES);
+  for (int i = 0; i < spec->n_alternatives; ++i) {
+    const swb_alternative& alt = spec->alternatives[i];
+    if (alt.n < 1 || alt.n > SWB_MAX_GROUPS) return fail(SWB_ERR_INVALID, "alternative %d: 1..%d groups", i, SWB_MAX_GROUPS);
+    for (int g = 0; g < alt.n; ++g)
+      if (alt.group[g] < 0 || alt.group[g] >= spec->n_groups) return fail(SWB_ERR_INVALID, "alternative %d: bad group index", i);
+  }
   int max_total = 0;
   for (int g = 0; g < spec->n_groups; ++g) {
     const swb_sprite_group& grp = spec->groups[g];
@@ -409,6 +420,14 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
       if (grp.shapes[i] < 0 || grp.shapes[i] >= SWB_MAX_SHAPES) return fail(SWB_ERR_INVALID, "group %d: bad shape index", g);
     max_total += grp.count_max;
   }
+  if (spec->n_alternatives > 0) {
+    max_total = 0;
+    for (int i = 0; i < spec->n_alternatives; ++i) {
+      int tot = 0;
+      for (int g = 0; g < spec->alternatives[i].n; ++g) tot += spec->groups[spec->alternatives[i].group[g]].count_max;
+      if (tot > max_total) max_total = tot;
+    }
+  }
   if (max_total > S) return fail(SWB_ERR_INVALID, "sampler can emit %d sprites (max_sprites %d)", max_total, S);
   for (int i = 0; i < N; ++i)
     if (pool_len_host[i] < 1 || pool_base_host[i] < 0 || pool_base_host[i] + pool_len_host[i] > P)
@@ -435,7 +454,7 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
   p.p_scale = h->d_p_scale; p.p_ca = h->d_p_ca; p.p_sa = h->d_p_sa; p.p_shape = h->d_p_shape; p.p_rgb = h->d_p_rgb;
   p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
   p.p_angle = h->d_p_angle; p.p_color = h->d_p_color;
-  swb_sampler_args a{h->d_sampler, P, S, T, seed, first_entry, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale,
+  swb_sampler_args a{h->d_sampler, P, S, T, seed, first_entry, nullptr, nullptr, nullptr, N, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale,
                      h->d_p_ca, h->d_p_sa, h->d_p_angle, h->d_p_color, h->d_p_shape, h->d_p_rgb, h->d_p_label};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(swb_sample_pool_kernel, dim3((P + 255) / 256), dim3(256), 0, st, a);
@@ -444,6 +463,25 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
   HIP_TRY(hipMemsetAsync(h->d_episode, 0, sizeof(int32_t) * N, st));
   HIP_TRY(hipMemsetAsync(h->d_step_count, 0, sizeof(int32_t) * N, st));
   h->have_pool = true;
+  h->pool_sampled = true;
+  h->pool_uniform = true;
+  for (int i = 0; i < N; ++i)
+    if (pool_len_host[i] != pool_len_host[0] || pool_base_host[i] != i * pool_len_host[0]) h->pool_uniform = false;
+  return SWB_OK;
+}
+
+int swb_resample_pool(swb_handle h, uint64_t seed, uint64_t first_entry, void* stream) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  if (!h->have_pool || !h->pool_sampled) return fail(SWB_ERR_STATE, "swb_sample_pool has not been called");
+  if (!h->pool_uniform)
+    return fail(SWB_ERR_STATE, "swb_resample_pool needs the env-major layout pool_base[n] = n * pool_len, equal pool_len");
+  HIP_TRY(hipSetDevice(h->device));
+  const int P = h->pool_entries, S = h->p.S, T = h->p.n_tasks, N = h->p.N;
+  swb_sampler_args a{h->d_sampler, P, S, T, seed, first_entry, h->d_entry, h->d_pool_base, h->d_pool_len, N, h->d_p_n,
+                     h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa, h->d_p_angle,
+                     h->d_p_color, h->d_p_shape, h->d_p_rgb, h->d_p_label};
+  hipLaunchKernelGGL(swb_sample_pool_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
   return SWB_OK;
 }
 

@@ -96,9 +96,13 @@ def _marginals(dist, holdouts=None):
 
 class DeviceSampler(object):
   """`groups`: list of (factor_distribution, num_sprites); num_sprites is an int or a (lo, hi)
-  pair meaning np.random.randint(lo, hi).  `shuffle`: sprite_generators.shuffle of the z-order."""
+  pair meaning np.random.randint(lo, hi).  `shuffle`: sprite_generators.shuffle of the z-order --
+  True: all sprites; an int k: only the sprites of the first k groups (the rest keep their place
+  on top, like the agent body of examples/goal_finding_embodied.py:88-93).  `alternatives`:
+  sprite_generators.sample_generator -- a list of lists of group indices; each episode generates
+  the groups of one list chosen uniformly (default: all groups, in order)."""
 
-  def __init__(self, groups, shuffle=False, seed=0):
+  def __init__(self, groups, shuffle=False, seed=0, alternatives=None):
     self.groups, self._holdouts = [], []
     for dist, count in groups:
       if isinstance(count, (tuple, list)):
@@ -115,13 +119,25 @@ class DeviceSampler(object):
       self._holdouts.append(holdouts)
     if not 1 <= len(self.groups) <= _abi.SWB_MAX_GROUPS:
       raise LoweringError('1..%d sprite groups are supported' % _abi.SWB_MAX_GROUPS)
-    self.shuffle = bool(shuffle)
+    self.shuffle = _abi.SWB_MAX_GROUPS if shuffle is True else int(shuffle)
+    if self.shuffle < 0:
+      raise ValueError('shuffle must be a bool or a number of leading groups')
+    self.alternatives = None if alternatives is None else [list(map(int, a)) for a in alternatives]
+    if self.alternatives is not None:
+      if not 1 <= len(self.alternatives) <= _abi.SWB_MAX_ALTERNATIVES:
+        raise LoweringError('1..%d alternatives are supported' % _abi.SWB_MAX_ALTERNATIVES)
+      for a in self.alternatives:
+        if not 1 <= len(a) <= _abi.SWB_MAX_GROUPS or not all(0 <= g < len(self.groups) for g in a):
+          raise ValueError('bad alternative %r' % (a,))
     self.seed = int(seed)
     self._draws = 0
 
+  def _lists(self):
+    return self.alternatives if self.alternatives is not None else [list(range(len(self.groups)))]
+
   @property
   def max_sprites(self):
-    return sum(hi for _, _, hi, _ in self.groups)
+    return max(sum(self.groups[g][2] for g in lst) for lst in self._lists())
 
   def next_seed(self):
     """A fresh 64-bit Philox key per pool (splitmix64 of seed and draw counter)."""
@@ -133,13 +149,18 @@ class DeviceSampler(object):
 
   # ---------------------------------------------------------------- host sampling (numpy)
   def __call__(self):
-    sprites = []
-    for dist, lo, hi, _ in self.groups:
+    lists = self._lists()
+    chosen = lists[np.random.randint(len(lists))] if len(lists) > 1 else lists[0]
+    sprites, n_shuffled = [], 0
+    for g, gi in enumerate(chosen):
+      dist, lo, hi, _ = self.groups[gi]
       n = lo if lo == hi else np.random.randint(lo, hi + 1)
       sprites.extend(sprite_lib.Sprite(**dist.sample()) for _ in range(n))
-    if self.shuffle:
-      order = np.random.permutation(len(sprites))
-      sprites = [sprites[i] for i in order]
+      if g < self.shuffle:
+        n_shuffled = len(sprites)
+    if n_shuffled > 1:
+      order = np.random.permutation(n_shuffled)
+      sprites = [sprites[i] for i in order] + sprites[n_shuffled:]
     return sprites
 
   # ---------------------------------------------------------------- lowering
@@ -172,7 +193,12 @@ class DeviceSampler(object):
     from spriteworld_amd import lowering
     spec = _abi.SwbSampler()
     spec.n_groups = len(self.groups)
-    spec.shuffle = int(self.shuffle)
+    spec.shuffle = self.shuffle
+    spec.n_alternatives = 0 if self.alternatives is None else len(self.alternatives)
+    for i, lst in enumerate(self.alternatives or []):
+      spec.alternatives[i].n = len(lst)
+      for j, g in enumerate(lst):
+        spec.alternatives[i].group[j] = g
     _, pil = lowering.find_pil_renderer(renderers)
     to_rgb = getattr(pil, '_color_to_rgb', None) if pil is not None else None
     probe = (0.3, 0.6, 0.9)
@@ -230,3 +256,75 @@ class DeviceSampler(object):
       for t, sub in enumerate(subs):
         grp.label[t] = self._group_label(sub, dist, marg)
     return spec
+
+
+# ------------------------------------------------------------------------------ closures -> sampler
+def _closure(fn):
+  return dict(zip(fn.__code__.co_freevars, (c.cell_contents for c in fn.__closure__ or ())))
+
+
+def _count_of(num_sprites):
+  """int, or the (lo, hi) of a `lambda: np.random.randint(lo, hi)` (cobra/exploration.py:58)."""
+  if not callable(num_sprites):
+    return int(num_sprites)
+  code = getattr(num_sprites, '__code__', None)
+  if code is not None and code.co_argcount == 0 and code.co_names[-1:] == ('randint',):
+    ints = [c for c in code.co_consts if isinstance(c, int) and not isinstance(c, bool)]
+    if len(ints) == 2 and not num_sprites.__closure__:
+      return (ints[0], ints[1])
+  raise LoweringError('num_sprites callable is not a plain `lambda: np.random.randint(lo, hi)`')
+
+
+def _flatten(fn):
+  """Generator closure -> (groups, n_leading_groups_shuffled or None, alternatives or None)."""
+  kind = getattr(fn, '__qualname__', '').split('.')[0]
+  cells = _closure(fn) if getattr(fn, '__code__', None) is not None else {}
+  if kind == 'generate_sprites':
+    return [(cells['factor_dist'], _count_of(cells['num_sprites']))], None, None
+  if kind == 'shuffle':
+    groups, inner, alts = _flatten(cells.get('sprite_generator', cells.get('generator')))
+    if inner is not None:
+      raise LoweringError('shuffle of an already shuffled generator is not sampled on the device')
+    return groups, _abi.SWB_MAX_GROUPS, alts
+  if kind == 'chain_generators':
+    gens = cells.get('sprite_generators', cells.get('generators'))
+    groups, shuffled = [], None
+    for i, g in enumerate(gens):
+      sub, sh, alts = _flatten(g)
+      if alts is not None:
+        raise LoweringError('sample_generator inside chain_generators is not sampled on the device')
+      if sh is not None:
+        if i != 0:
+          raise LoweringError('only a leading shuffled sub-generator is sampled on the device')
+        shuffled = len(sub)
+      groups.extend(sub)
+    return groups, shuffled, None
+  if kind == 'sample_generator':
+    if cells.get('p') is not None:
+      raise LoweringError('weighted sample_generator is not sampled on the device')
+    groups, alts, seen = [], [], {}
+    for g in cells.get('sprite_generators', cells.get('generators')):
+      sub, sh, inner = _flatten(g)
+      if sh is not None or inner is not None:
+        raise LoweringError('nested shuffle / sample_generator is not sampled on the device')
+      lst = []
+      for dist, count in sub:                  # the same (distribution, count) is one group
+        key = (id(dist), count)
+        if key not in seen:
+          seen[key] = len(groups)
+          groups.append((dist, count))
+        lst.append(seen[key])
+      alts.append(lst)
+    return groups, None, alts
+  raise LoweringError('%r is not built from generate_sprites / chain_generators / sample_generator / shuffle' % (fn,))
+
+
+def from_generator(init_sprites, seed=0):
+  """DeviceSampler equivalent to a generator built with the reference's (or this package's)
+  `sprite_generators.generate_sprites / chain_generators / sample_generator / shuffle`, by reading
+  their closures.  Raises LoweringError for anything else (hand-written callables, weighted
+  choices, ...)."""
+  if isinstance(init_sprites, DeviceSampler):
+    return init_sprites
+  groups, shuffled, alts = _flatten(init_sprites)
+  return DeviceSampler(groups, shuffle=shuffled or 0, seed=seed, alternatives=alts)

@@ -97,6 +97,11 @@ class Engine(object):
     self.pool = None
     self._pool_entries = int(n_entries)
 
+  def resample_pool(self, seed, first_entry=0):
+    """Fresh episodes in every pool entry no environment is playing; nothing is reset (swb_resample_pool)."""
+    _lib.check(self.lib.swb_resample_pool(self._h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF),
+                                          C.c_uint64(int(first_entry)), self._stream()))
+
   def get_pool(self):
     """Host copy (lowering.Pool) of the pool the device currently holds."""
     from spriteworld_amd import lowering

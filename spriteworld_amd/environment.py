@@ -45,7 +45,7 @@ class BatchedEnvironment(object):
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, num_envs=1, episodes_per_env=8,
                max_sprites=None, device=0, check_errors=32, action_dtype=np.float64,
-               global_env_offset=0):
+               global_env_offset=0, device_reset=False):
     self._task = task
     self._action_space = action_space
     self._renderers = renderers
@@ -70,7 +70,19 @@ class BatchedEnvironment(object):
                    if k != self._image_key and k not in self._success_keys and k not in self._factor_keys]
     if unsupported:
       raise lowering.LoweringError('renderers not supported on device: %s' % unsupported)
+    # Episodes are drawn on the device when init_sprites is a DeviceSampler, or -- device_reset=True /
+    # 'auto' -- when it was built with sprite_generators.* from Product/SetMinus/Continuous/Discrete
+    # distributions (the generator's closures are read, device_sampler.from_generator); 'auto' falls
+    # back to calling init_sprites() on the host when that is not possible.
     self._sampler = init_sprites if isinstance(init_sprites, device_sampler.DeviceSampler) else None
+    if self._sampler is None and device_reset:
+      try:
+        sampler = device_sampler.from_generator(init_sprites)
+        sampler.lower(task, renderers)
+        self._sampler = sampler
+      except lowering.LoweringError:
+        if device_reset != 'auto':
+          raise
     if self._sampler is not None:   # episodes are drawn by the engine (swb_sample_pool)
       episodes = None
       S = max_sprites or max(self._sampler.max_sprites, 1)
@@ -117,6 +129,14 @@ class BatchedEnvironment(object):
                                    max_sprites=self._max_sprites)
     pool.assign_round_robin(self._num_envs, self._episodes_per_env)
     self._engine.set_pool(pool)
+
+  def refresh_pool(self):
+    """DeviceSampler only: redraws every pool entry that no environment is playing right now, without
+    resetting anything.  Called every few episodes, environments never meet an episode twice."""
+    if self._sampler is None:
+      raise lowering.LoweringError('refresh_pool() needs init_sprites to be a device_sampler.DeviceSampler')
+    self._engine.resample_pool(self._sampler.next_seed(),
+                               first_entry=self._global_env_offset * self._episodes_per_env)
 
   # ------------------------------------------------------------------ dm_env surface
   @property
@@ -231,11 +251,12 @@ class Environment(object):
 
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, episodes_per_pool=32, device=0,
-               action_dtype=np.float64):
+               action_dtype=np.float64, device_reset=False):
     self._batched = BatchedEnvironment(
         task, action_space, renderers, init_sprites, keep_in_frame=keep_in_frame,
         max_episode_length=max_episode_length, metadata=metadata, num_envs=1,
-        episodes_per_env=episodes_per_pool, device=device, action_dtype=action_dtype, check_errors=1)
+        episodes_per_env=episodes_per_pool, device=device, action_dtype=action_dtype, check_errors=1,
+        device_reset=device_reset)
     self._episodes_per_pool = episodes_per_pool
     self._episodes_used = 0
     self._reset_next_step = True

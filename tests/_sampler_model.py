@@ -61,23 +61,29 @@ def sample_pool(spec, n_entries, max_sprites, seed, to_rgb, label_fns, shape_nam
              color=np.zeros((P, S, 3)), label=np.zeros((P, T, S), np.int8))
   for e in range(P):
     rng = Stream(seed, first_entry + e)
+    if spec.n_alternatives > 0:
+      alt = spec.alternatives[rng.u32() % spec.n_alternatives if spec.n_alternatives > 1 else 0]
+      order = [alt.group[g] for g in range(alt.n)]
+    else:
+      order = list(range(spec.n_groups))
     counts, n = [], 0
-    for g in range(spec.n_groups):
+    for g in order:
       grp = spec.groups[g]
       c = grp.count_min + rng.u32() % (grp.count_max - grp.count_min + 1)
       c = min(c, S - n)
       counts.append(c)
       n += c
     slot = list(range(16))
-    if spec.shuffle:
-      for i in range(n - 1, 0, -1):
+    m = sum(counts[:spec.shuffle])
+    if m > 1:
+      for i in range(m - 1, 0, -1):
         j = rng.u32() % (i + 1)
         slot[i], slot[j] = slot[j], slot[i]
     out['n_sprites'][e] = n
     k = 0
-    for g in range(spec.n_groups):
+    for gi, g in enumerate(order):
       grp = spec.groups[g]
-      for _ in range(counts[g]):
+      for _ in range(counts[gi]):
         s = slot[k]
         k += 1
         fv = [None] * _abi.SWB_N_FACTORS

@@ -90,7 +90,43 @@ def _holdouts():
   return sampler, task, rend
 
 
-CASES = {'cobra_like': _cobra_like, 'mixed_types': _mixed_types, 'hsv_mixed': _hsv_mixed, 'holdouts': _holdouts}
+def _embodied_like():
+  """A shuffled set of objects with the agent body kept on top (examples/goal_finding_embodied.py:68-93)."""
+  obj = distribs.Product([distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9),
+                          distribs.Discrete('shape', ['square', 'triangle', 'circle']), distribs.Discrete('scale', [0.13]),
+                          distribs.Continuous('c1', 0.3, 1.), distribs.Continuous('c2', 0.9, 1.)])
+  target = distribs.Product([obj, distribs.Continuous('c0', 0., 0.4)])
+  distractor = distribs.Product([obj, distribs.Continuous('c0', 0.5, 0.9)])
+  body = distribs.Product([distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9),
+                           distribs.Discrete('shape', ['circle']), distribs.Discrete('scale', [0.07]),
+                           distribs.Discrete('c0', [0.2]), distribs.Discrete('c1', [1.]), distribs.Discrete('c2', [1.])])
+  sampler = device_sampler.DeviceSampler([(target, 1), (distractor, (0, 3)), (body, 1)], shuffle=2, seed=5)
+  task = tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.4), terminate_distance=0.1)
+  rend = {'image': renderer_lib.PILRenderer(image_size=(64, 64), anti_aliasing=5,
+                                            color_to_rgb=renderer_lib.color_maps.hsv_to_rgb)}
+  return sampler, task, rend
+
+
+def _sorting_like():
+  """shuffle(sample_generator(chains)) over shared single-sprite groups (cobra/sorting.py:75-115)."""
+  hues = [distribs.Continuous('c0', lo, lo + 0.1) for lo in (0.05, 0.25, 0.45, 0.65, 0.85)]
+  goals = [(0.75, 0.75), (0.25, 0.75), (0.25, 0.25), (0.75, 0.25), (0.5, 0.5)]
+  groups = [(distribs.Product((h, distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9),
+                               distribs.Discrete('shape', ['square', 'triangle', 'circle']),
+                               distribs.Discrete('scale', [0.13]), distribs.Continuous('c1', 0.3, 1.),
+                               distribs.Continuous('c2', 0.9, 1.))), 1) for h in hues]
+  import itertools
+  combos = [list(c) for c in itertools.combinations(range(5), 2)][1:]
+  sampler = device_sampler.DeviceSampler(groups, shuffle=True, seed=9, alternatives=combos)
+  subtasks = [tasks.FindGoalPosition(filter_distrib=h, goal_position=g, terminate_distance=0.1, raw_reward_multiplier=20)
+              for h, g in zip(hues, goals)]
+  task = tasks.MetaAggregated(subtasks, reward_aggregator='sum', termination_criterion='all')
+  rend = {'image': renderer_lib.PILRenderer(image_size=(64, 64), anti_aliasing=5,
+                                            color_to_rgb=renderer_lib.color_maps.hsv_to_rgb)}
+  return sampler, task, rend
+
+
+CASES = {'sorting_like': _sorting_like, 'embodied_like': _embodied_like, 'cobra_like': _cobra_like, 'mixed_types': _mixed_types, 'hsv_mixed': _hsv_mixed, 'holdouts': _holdouts}
 
 
 def test_philox_known_answers():
@@ -108,11 +144,14 @@ def test_lowering_fills_the_spec(case):
   spec = sampler.lower(task, rend)
   assert spec.n_groups == len(sampler.groups)
   assert spec.deg_cos[90] == np.cos(np.radians(90)) and spec.deg_sin[270] == np.sin(np.radians(270))
+  if case == 'sorting_like':
+    assert spec.n_alternatives == 9 and spec.alternatives[0].n == 2 and sampler.max_sprites == 2
+    assert [spec.groups[g].label[g] for g in range(5)] == [1] * 5 and spec.groups[0].label[1] == 0
   for g in range(spec.n_groups):
     assert spec.groups[g].factor('x').kind == _abi.FACTOR_UNIFORM_F32
     assert 1 <= spec.groups[g].n_shapes <= _abi.SWB_MAX_CANDIDATES
   if case == 'cobra_like':
-    assert spec.color_map == 1 and spec.shuffle == 1
+    assert spec.color_map == 1 and spec.shuffle == _abi.SWB_MAX_GROUPS
     assert [spec.groups[g].label[0] for g in range(2)] == [1, 0]
     assert (spec.groups[1].count_min, spec.groups[1].count_max) == (1, 3)
     assert sampler.max_sprites == 5
@@ -141,6 +180,90 @@ def test_setminus_lowers_to_holdout_boxes():
   assert not ((tx >= 0.5) & (ty >= 0.5)).any() and ((tx >= 0.5) | (ty >= 0.5)).any()
   assert not ((ts >= 0.08) & (ts < 0.12)).any() and (ts < 0.08).any() and (ts >= 0.12).any()
   assert ((got['x'][:, 2] >= 0.5) & (got['y'][:, 2] >= 0.5)).any()      # distractors are not held out
+
+
+def test_partial_shuffle_keeps_the_body_on_top():
+  sampler, task, rend = _embodied_like()
+  spec = sampler.lower(task, rend)
+  assert spec.shuffle == 2 and spec.n_groups == 3
+  label = lambda f: int(task._filter_distrib.contains(f))
+  got = _sampler_model.sample_pool(spec, 600, 4, 17, rend['image']._color_to_rgb, [label], shapes.SHAPE_NAMES)
+  n = got['n_sprites']
+  top = got['scale'][np.arange(600), n - 1]
+  assert (top == 0.07).all()                                         # body always last (front-most)
+  first_is_target = got['label'][n == 3, 0, 0].mean()                # 1 target among 2 shuffled objects
+  assert abs(first_is_target - 0.5) < 0.1
+  np.random.seed(0)
+  for _ in range(30):
+    sprites = sampler()
+    assert sprites[-1].scale == 0.07 and 2 <= len(sprites) <= 4
+
+
+def test_from_generator_reads_generator_closures():
+  from spriteworld_amd import sprite_generators as gens
+  a = distribs.Product([distribs.Continuous('x', 0., 1.), distribs.Continuous('y', 0., 1.)])
+  b = distribs.Product([distribs.Continuous('x', 0., 1.), distribs.Continuous('y', 0., 1.), distribs.Discrete('scale', [0.2])])
+  s = device_sampler.from_generator(gens.shuffle(gens.chain_generators(
+      gens.generate_sprites(a, num_sprites=2), gens.generate_sprites(b, num_sprites=lambda: np.random.randint(1, 4)))))
+  assert [(lo, hi) for _, lo, hi, _ in s.groups] == [(2, 2), (1, 3)] and s.shuffle == _abi.SWB_MAX_GROUPS
+  s = device_sampler.from_generator(gens.chain_generators(
+      gens.shuffle(gens.chain_generators(gens.generate_sprites(a, 1), gens.generate_sprites(b, 2))),
+      gens.generate_sprites(b, 1)))
+  assert len(s.groups) == 3 and s.shuffle == 2
+  assert device_sampler.from_generator(gens.generate_sprites(a, 3)).shuffle == 0
+  ga, gb = gens.generate_sprites(a, 1), gens.generate_sprites(b, 1)
+  s = device_sampler.from_generator(gens.shuffle(gens.sample_generator(
+      [gens.chain_generators(ga, gb), gens.chain_generators(gb, ga), ga])))
+  assert len(s.groups) == 2 and s.alternatives == [[0, 1], [1, 0], [0]] and s.max_sprites == 2
+  with pytest.raises(lowering.LoweringError):
+    device_sampler.from_generator(gens.sample_generator([ga, gb], p=[0.3, 0.7]))
+  with pytest.raises(lowering.LoweringError):
+    device_sampler.from_generator(lambda: [])
+  with pytest.raises(lowering.LoweringError):
+    device_sampler.from_generator(gens.generate_sprites(a, num_sprites=lambda: 3))
+  with pytest.raises(lowering.LoweringError):     # shuffled part not leading
+    device_sampler.from_generator(gens.chain_generators(gens.generate_sprites(a, 1), gens.shuffle(gens.generate_sprites(b, 2))))
+
+
+def test_every_reference_config_lowers_to_a_device_sampler():
+  """from_generator + lower on the reference's own config dicts (both modes): the label probing, the
+  SetMinus hold-outs, integer colours / angles and the partially shuffled embodied generator."""
+  from oracle import ref_harness
+  if not ref_harness.reference_available():
+    pytest.skip('reference tree not present')
+  import importlib
+  ref_harness.load_reference()
+  expect_groups = {'goal_finding_new_position': 2, 'goal_finding_new_shape': 1, 'goal_finding_more_distractors': 2,
+                   'goal_finding_more_targets': 2, 'clustering': 2, 'sorting': None, 'exploration': 1,
+                   'goal_finding_embodied': 3}
+  np.random.seed(0)
+  for pkg in ('cobra', 'examples'):
+    for name, n_groups in expect_groups.items():
+      try:
+        mod = importlib.import_module('spriteworld.configs.%s.%s' % (pkg, name))
+      except ImportError:
+        continue
+      for mode in ('train', 'test'):
+        config = mod.get_config(mode)
+        sampler = device_sampler.from_generator(config['init_sprites'])
+        spec = sampler.lower(config['task'], config['renderers'])
+        assert spec.n_groups == (n_groups or (5 if mode == 'train' else 2)), (name, mode)
+        if name == 'goal_finding_embodied':
+          assert spec.shuffle == 2
+        if name == 'sorting':
+          assert spec.n_alternatives == (9 if mode == 'train' else 0)
+        if name == 'goal_finding_new_position' and mode == 'train':
+          assert spec.groups[0].n_holdouts == 1
+        # host episodes of the same generator fit the sampler's bounds
+        for _ in range(5):
+          assert len(config['init_sprites']()) <= sampler.max_sprites
+  # examples/goal_finding_clustering mixes random counts, integer colours and a SetMinus scale
+  mod = importlib.import_module('spriteworld.configs.examples.goal_finding_clustering')
+  for mode in ('train', 'test'):
+    config = mod.get_config(mode)
+    sampler = device_sampler.from_generator(config['init_sprites'])
+    spec = sampler.lower(config['task'], config['renderers'])
+    assert spec.color_map == 0 and spec.n_groups >= 4
 
 
 def test_host_call_draws_valid_sprites():
@@ -248,6 +371,62 @@ def test_sampled_environment_steps_like_one_built_from_the_same_pool():
   env.check()
   env.close()
   twin.close()
+
+
+@pytest.mark.gpu
+def test_device_reset_option_reads_the_generator_closures():
+  from spriteworld_amd import environment
+  from tests import test_host_api
+  config = test_host_api._cobra_like_config(n_targets=2, n_distractors=1)
+  env = environment.BatchedEnvironment(num_envs=256, episodes_per_env=4, device_reset=True, **config)
+  assert env._sampler is not None and env._sampler.max_sprites == 3
+  pool = env.engine.get_pool()
+  assert (pool.n_sprites == 3).all() and (pool.label.sum(axis=2) == 2).all()       # two targets per episode
+  ts = env.reset()
+  for _ in range(30):
+    ts = env.step(env.sample_actions())
+  env.check()
+  env.close()
+  single = environment.Environment(device_reset='auto', **config)
+  ts = single.reset()
+  assert ts.first() and ts.observation['image'].shape == (64, 64, 3)
+  single.close()
+  config['init_sprites'] = lambda: test_host_api._cobra_like_config()['init_sprites']()
+  with pytest.raises(lowering.LoweringError):
+    environment.BatchedEnvironment(num_envs=4, device_reset=True, **config)
+  env = environment.BatchedEnvironment(num_envs=4, device_reset='auto', **config)     # host fallback
+  assert env._sampler is None
+  env.close()
+
+
+@pytest.mark.gpu
+def test_refresh_pool_redraws_everything_but_the_live_entries():
+  import torch
+  env, sampler, task, rend = _make_env('cobra_like', num_envs=64, episodes_per_env=4)
+  env.reset()
+  for _ in range(9):                      # max_episode_length = 6: every env is in its 2nd episode
+    env.step(env.sample_actions())
+  before = env.engine.get_pool()
+  st = env.state()
+  frame = env.observation()['image'].clone()
+  env.refresh_pool()
+  after = env.engine.get_pool()
+  live = st['pool_entry']
+  assert np.array_equal(live // 4, np.arange(64))
+  changed = (before.x != after.x).any(axis=1)
+  assert not changed[live].any() and changed[np.setdiff1d(np.arange(256), live)].all()
+  st2 = env.state()
+  assert np.array_equal(st2['step_count'], st['step_count']) and np.array_equal(st2['x'], st['x'])
+  assert torch.equal(env.observation()['image'], frame)             # nothing visible changed
+  # stepping on: the next episodes come from the refreshed entries
+  for _ in range(8):                      # a LAST and the FIRST after it, for every environment
+    env.step(env.sample_actions())
+  st3 = env.state()
+  moved = st3['pool_entry'] != live
+  assert moved.all()
+  np.testing.assert_array_equal(env.engine.get_pool().shape[st3['pool_entry']], after.shape[st3['pool_entry']])
+  env.check()
+  env.close()
 
 
 @pytest.mark.gpu
