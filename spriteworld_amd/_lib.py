@@ -10,7 +10,8 @@ import os
 from spriteworld_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libswb.so')
+# SWB_LIBRARY: an alternative build of the same ABI (experiments, integrators' own install path)
+LIB_PATH = os.environ.get('SWB_LIBRARY') or os.path.join(_HERE, 'csrc', 'libswb.so')
 
 # Every symbol include/swb.h declares (tests check the library exports them all).
 EXPORTS = (
