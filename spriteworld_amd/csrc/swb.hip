@@ -131,6 +131,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   const variant* v = pick_variant(h->p.Wc, h->p.Wo, h->vslots);
   if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d / image width %d not supported", h->p.Wc, h->p.Hc, h->p.Wo);
   swb_params p = h->p;
+  if (p.v_tab && v->vs == 8) p.v_tab += (size_t)p.Hc * SWB_VSLOTS;   // slot table of this variant's VS
   p.actions = actions;
   p.obs = out ? out->obs : nullptr;
   p.reward = out ? out->reward : nullptr;
@@ -301,7 +302,11 @@ int swb_upload_resample(swb_handle h, int32_t axis, int32_t out_size, int32_t ks
     h->have_h = true;
   } else if (axis == 1) {
     if (out_size != p.Ho) return fail(SWB_ERR_INVALID, "vertical table has %d outputs, image height is %d", out_size, p.Ho);
-    std::vector<int32_t> vend(out_size), vtab((size_t)p.Hc * SWB_VSLOTS, 0);
+    // v_tab holds two tables of [Hc][SWB_VSLOTS]: output row r accumulates in slot r % 6 (first table,
+    // kernels with VS = 6) or r % 8 (second table, VS = 8), so the in-flight rows never move between
+    // accumulators; the rows in flight at a canvas row are consecutive, hence in distinct slots.
+    const size_t tab_len = (size_t)p.Hc * SWB_VSLOTS;
+    std::vector<int32_t> vend(out_size), vtab(2 * tab_len, 0);
     for (int r = 0; r < out_size; ++r) {
       const int ymin = bounds[2 * r], c = bounds[2 * r + 1];
       if (c < 1 || c > ksize || ymin < 0 || ymin + c > p.Hc) return fail(SWB_ERR_INVALID, "bad vertical bounds at %d", r);
@@ -317,7 +322,9 @@ int swb_upload_resample(swb_handle h, int32_t axis, int32_t out_size, int32_t ks
         if (y < ymin || y > vend[r]) continue;
         const int k = r - rf;
         if (k < 0 || k >= SWB_VSLOTS) return fail(SWB_ERR_INVALID, "more than %d output rows in flight at canvas row %d", SWB_VSLOTS, y);
-        vtab[(size_t)y * SWB_VSLOTS + k] = coeffs[(size_t)r * ksize + (y - ymin)];
+        const int32_t cf = coeffs[(size_t)r * ksize + (y - ymin)];
+        vtab[(size_t)y * SWB_VSLOTS + (r % 6)] = cf;           // only used when used <= 6
+        vtab[tab_len + (size_t)y * SWB_VSLOTS + (r % 8)] = cf;
         if (k + 1 > used) used = k + 1;
       }
     }
