@@ -59,6 +59,16 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     labels = [[0]] * 2 + [[1]] * 3
     pool = synthetic.make_pool(rng, P, 5, hues, labels)
     cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 5, True)
+  elif name == 'cluster6_s12':
+    # six clusters of two: more clusters than the wave-parallel Davies-Bouldin handles (scalar path),
+    # float32 positions; one sprite in no cluster
+    task = tasks.Clustering([None] * 6, termination_threshold=1.2, terminate_bonus=1., reward_range=6.)
+    aspace = action_spaces.SelectMove(scale=0.25)
+    rend = _renderers(64, aa)
+    hues = [(0.08 * i, 0.08 * i + 0.05) for i in range(6) for _ in range(2)] + [(0.9, 1.0)]
+    labels = [[i] for i in range(6) for _ in range(2)] + [[-1]]
+    pool = synthetic.make_pool(rng, P, 13, hues, labels, scales=(0.06, 0.09))
+    cfg = lowering.lower_config(task, aspace, rend, True, 30, num_envs, 13, True)
   elif name == 'embodied_s12':
     task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
     aspace = action_spaces.Embodied(step_size=0.05)

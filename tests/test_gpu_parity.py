@@ -80,6 +80,10 @@ def test_f64_sprites_clustering_three_clusters():
   _run('f64_cluster', 256, 40, 3)
 
 
+def test_six_clusters_scalar_davies_bouldin_path():
+  _run('cluster6_s12', 128, 25, 2)
+
+
 def test_cluster_s5_aa1():
   _run('cluster_s5', 128, 10, 1)
 
