@@ -45,7 +45,7 @@ class BatchedEnvironment(object):
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, num_envs=1, episodes_per_env=8,
                max_sprites=None, device=0, check_errors=32, action_dtype=np.float64,
-               global_env_offset=0, device_reset=False):
+               global_env_offset=0, device_reset=False, refresh_every=0):
     self._task = task
     self._action_space = action_space
     self._renderers = renderers
@@ -63,6 +63,10 @@ class BatchedEnvironment(object):
     # `check()` can be called at any time).
     self._check_errors = int(check_errors)
     self._steps_since_check = 0
+    # With device-side reset sampling: redraw the idle pool entries every `refresh_every` steps (0: never;
+    # refresh_pool() can be called by hand).  episodes_per_env * shortest episode length is a safe period.
+    self._refresh_every = int(refresh_every)
+    self._steps_since_refresh = 0
     self._image_key, self._pil = lowering.find_pil_renderer(renderers)
     self._success_keys = [k for k, r in renderers.items() if type(r).__name__ == 'Success']
     self._factor_keys = {k: r for k, r in renderers.items() if type(r).__name__ == 'SpriteFactors'}
@@ -224,6 +228,11 @@ class BatchedEnvironment(object):
       noise = torch.randn(actions.shape, dtype=torch.float64, device=e.device, generator=self._noise_gen)
       actions = (actions.to(torch.float64) + noise * self._noise_scale.to(e.device)).to(actions.dtype)
     self._engine.step(actions, render=self._render)
+    if self._refresh_every and self._sampler is not None:
+      self._steps_since_refresh += 1
+      if self._steps_since_refresh >= self._refresh_every:
+        self._steps_since_refresh = 0
+        self.refresh_pool()
     return self._timestep()
 
   def observation(self):

@@ -430,6 +430,30 @@ def test_refresh_pool_redraws_everything_but_the_live_entries():
 
 
 @pytest.mark.gpu
+def test_refresh_every_keeps_episodes_fresh():
+  """With refresh_every the same (env, pool slot) never serves the same episode twice."""
+  from spriteworld_amd import environment
+  sampler, task, rend = _cobra_like()
+  env = environment.BatchedEnvironment(task=task, action_space=action_spaces.SelectMove(scale=0.25), renderers=rend,
+                                       init_sprites=sampler, max_episode_length=4, num_envs=32, episodes_per_env=2,
+                                       refresh_every=5)
+  env.reset()
+  seen = set()
+  for _ in range(40):
+    ts = env.step(env.sample_actions())
+    first = (ts.step_type == 0).cpu().numpy()
+    if first.any():
+      st = env.state()
+      for e in np.flatnonzero(first):
+        key = (int(e), tuple(np.round(st['x'][e], 6)))      # the episode's initial positions
+        assert key not in seen
+        seen.add(key)
+  assert len(seen) > 32 * 4
+  env.check()
+  env.close()
+
+
+@pytest.mark.gpu
 def test_refill_draws_new_statistically_uniform_episodes():
   env, sampler, task, rend = _make_env('cobra_like', num_envs=2048, episodes_per_env=4)
   a = env.engine.get_pool()
