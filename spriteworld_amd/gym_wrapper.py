@@ -92,114 +92,87 @@ def _spec_to_space(spec):
   raise ValueError('Unknown type for specs: {}'.format(spec))
 
 
-class GymWrapper(object):
-  """Gym interface of a single environment; observations keyed like the `renderers` dict."""
+class _GymSurface(object):
+  """What both wrappers share: lazily built spaces, attribute passthrough, the cached last frame."""
   metadata = {'render.modes': ['rgb_array']}
+  _leading = ()                      # leading axes of every observation (the batch axis, if any)
 
   def __init__(self, env):
     self._env = env
-    self._last_render = None
-    self._action_space = None
-    self._observation_space = None
-    self._env.reset()
+    self._frame = None
+    self._spaces = {}
+    self._env.reset()                # the reference resets on construction (gym_wrapper.py:58)
 
   def __getattr__(self, name):
     return getattr(self._env, name)
 
   @property
   def observation_space(self):
-    if self._observation_space is None:
-      self._observation_space = spaces.Dict({
-          key: spaces.Box(-np.inf, np.inf, value.shape, dtype=value.dtype)
-          for key, value in self._env.observation_spec().items()})
-    return self._observation_space
+    if 'obs' not in self._spaces:
+      self._spaces['obs'] = spaces.Dict({
+          key: spaces.Box(-np.inf, np.inf, self._leading + tuple(spec.shape), dtype=spec.dtype)
+          for key, spec in self._env.observation_spec().items()})
+    return self._spaces['obs']
 
   @property
   def action_space(self):
-    if self._action_space is None:
-      self._action_space = _spec_to_space(self._env.action_spec())
-    return self._action_space
-
-  def _process_obs(self, obs):
-    for k, v in obs.items():
-      obs[k] = np.asarray(v)
-      if obs[k].dtype == np.bool_:
-        obs[k] = obs[k].astype(np.float32)
-      if k == 'image':
-        self._last_render = obs[k]
-    return obs
-
-  def step(self, action):
-    time_step = self._env.step(action)
-    obs = self._process_obs(time_step.observation)
-    reward = time_step.reward or 0
-    done = time_step.last()
-    return obs, reward, done, {'discount': time_step.discount}
+    if 'act' not in self._spaces:
+      self._spaces['act'] = _spec_to_space(self._env.action_spec())
+    return self._spaces['act']
 
   def reset(self):
-    return self._process_obs(self._env.reset().observation)
+    return self._observations(self._env.reset().observation)
 
   def render(self, mode='rgb_array'):
-    del mode
-    return self._last_render
+    del mode                         # rendering always happens; this returns the last 'image'
+    return self._frame
+
+
+class GymWrapper(_GymSurface):
+  """Gym interface of a single environment (`environment.Environment`): numpy observations keyed
+  like the `renderers` dict, booleans as float32, `reward or 0`, `done = last()`."""
+
+  def _observations(self, obs):
+    out = {}
+    for key, value in obs.items():
+      value = np.asarray(value)
+      out[key] = value.astype(np.float32) if value.dtype == np.bool_ else value
+      if key == 'image':
+        self._frame = out[key]
+    return out
+
+  def step(self, action):
+    ts = self._env.step(action)
+    return self._observations(ts.observation), (ts.reward or 0), ts.last(), {'discount': ts.discount}
 
   def close(self):
     pass
 
 
-class BatchedGymWrapper(object):
+class BatchedGymWrapper(_GymSurface):
   """The same contract for N environments: tensors with a leading N axis, auto-reset included.
 
   An environment whose step returned done=True restarts on the next `step` (its action is ignored,
   like the reference's Environment, environment.py:90-91) and reports reward 0 on that FIRST step.
   """
-  metadata = {'render.modes': ['rgb_array']}
 
   def __init__(self, env):
-    self._env = env
-    self._last_render = None
-    self._action_space = None
-    self._observation_space = None
-    self._env.reset()
+    self._leading = (env.num_envs,)
+    super(BatchedGymWrapper, self).__init__(env)
 
-  def __getattr__(self, name):
-    return getattr(self._env, name)
-
-  @property
-  def observation_space(self):
-    if self._observation_space is None:
-      n = self._env.num_envs
-      self._observation_space = spaces.Dict({
-          key: spaces.Box(-np.inf, np.inf, (n,) + tuple(value.shape), dtype=value.dtype)
-          for key, value in self._env.observation_spec().items()})
-    return self._observation_space
-
-  @property
-  def action_space(self):
-    if self._action_space is None:
-      self._action_space = _spec_to_space(self._env.action_spec())
-    return self._action_space
-
-  def _process_obs(self, obs):
+  def _observations(self, obs):
     out = {}
-    for k, v in obs.items():
-      out[k] = v.to(torch.float32) if v.dtype == torch.bool else v
-      if k == 'image':
-        self._last_render = out[k]
+    for key, value in obs.items():
+      out[key] = value.to(torch.float32) if value.dtype == torch.bool else value
+      if key == 'image':
+        self._frame = out[key]
     return out
 
   def step(self, actions):
     ts = self._env.step(actions)
     reward = torch.nan_to_num(ts.reward, nan=0.0)           # `reward or 0`
     done = ts.step_type == int(dm_env.StepType.LAST)
-    return self._process_obs(ts.observation), reward, done, {'discount': ts.discount}
-
-  def reset(self):
-    return self._process_obs(self._env.reset().observation)
-
-  def render(self, mode='rgb_array'):
-    del mode
-    return self._last_render
+    return self._observations(ts.observation), reward, done, {'discount': ts.discount}
 
   def close(self):
     self._env.close()
