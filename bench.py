@@ -229,6 +229,9 @@ def main():
         'cluster_s5_aa1': ('cluster_s5', args.envs_per_gpu, 1),
         'goal_s5_1024_aa5': ('goal_s5', 1024, 5),
         'embodied_s12_128_aa5': ('embodied_s12', args.envs_per_gpu, 5),
+        # BASELINE configs[3]'s per-GPU share is 8192; this is the same scene with 8x the batch in ONE launch
+        # (the launch's fixed fill/drain cost amortised)
+        'cluster_s5_65536_aa5': ('cluster_s5', 65536, 5),
     }.items():
       r = gpu_run(nm, n, short, 5, aa, device)
       ks = r['kernel_ms'] / 1e3 / max(r['launches'], 1)
