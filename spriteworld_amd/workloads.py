@@ -69,6 +69,17 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     labels = [[i] for i in range(6) for _ in range(2)] + [[-1]]
     pool = synthetic.make_pool(rng, P, 13, hues, labels, scales=(0.06, 0.09))
     cfg = lowering.lower_config(task, aspace, rend, True, 30, num_envs, 13, True)
+  elif name.startswith('geom_'):
+    # image geometry sweep: geom_<W>x<H> (non-square, wide images; anti_aliasing from the argument)
+    w, h = (int(v) for v in name[len('geom_'):].split('x'))
+    task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
+    aspace = action_spaces.SelectMove(scale=0.3)
+    rend = {'image': renderers.PILRenderer(image_size=(w, h), anti_aliasing=aa, bg_color=(7, 30, 110),
+                                           color_to_rgb=renderers.hsv_to_rgb)}
+    pool = synthetic.make_pool(rng, P, 4, [(0.0, 1.0)] * 4, [[1], [0], [1], [0]],
+                               shape_names=('square', 'triangle', 'circle', 'star_5', 'spoke_4'),
+                               scales=(0.1, 0.2, 0.4), angles=tuple(range(0, 360, 23)), xy_range=(0.0, 1.0))
+    cfg = lowering.lower_config(task, aspace, rend, True, 12, num_envs, 4, True)
   elif name == 'embodied_s12':
     task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
     aspace = action_spaces.Embodied(step_size=0.05)

@@ -109,3 +109,10 @@ def test_tiny_sprites_aa1():
 def test_float32_actions(name, aa):
   """Actions of the dtype action_spec() declares: float32 motion / click / cost arithmetic (NEP 50)."""
   _run(name, 192, 25, aa)
+
+
+@pytest.mark.parametrize('geom,aa', [('96x48', 3), ('48x96', 2), ('256x64', 2), ('160x160', 4), ('128x128', 1),
+                                     ('100x60', 3), ('64x256', 1), ('32x32', 8)])
+def test_image_geometries(geom, aa):
+  """Non-square and wide images: every kernel variant (canvas words x output columns x rows in flight)."""
+  _run('geom_' + geom, 48, 6, aa)
