@@ -82,7 +82,12 @@ def make(name, module, mode, n_eps, n_steps, seed, action_dtype='float64', motio
                               pos_is_f32=(pos_dt == np.float32), action_dtype=np.dtype(action_dtype))
   pool = lowering.lower_episodes(episodes, task, rends, max_sprites=S).assign_round_robin(1)
   # reference run, replaying the same episodes (the constructor draws once, environment.py:68)
-  it = iter([copy.deepcopy(episodes[0])] + [copy.deepcopy(e) for e in episodes] * 50)
+  def fresh():     # the constructor's own draw, then the pool order (wrapping) as new objects each time
+    yield copy.deepcopy(episodes[0])
+    while True:
+      for e in episodes:
+        yield copy.deepcopy(e)
+  it = fresh()
   config = dict(config)
   config['init_sprites'] = lambda: next(it)
   config['renderers'] = dict(rends)

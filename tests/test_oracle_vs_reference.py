@@ -26,6 +26,15 @@ _MODULES = [
 CONFIGS = [(m, mode) for m in _MODULES for mode in ('train', 'test')]
 
 
+def _fresh_episodes(episodes):
+  """What the reference's init_sprites must return to follow the pool: the constructor's own draw
+  (environment.py:68), then the episodes in order, wrapping around, as NEW sprite objects every time."""
+  yield copy.deepcopy(episodes[0])
+  while True:
+    for e in episodes:
+      yield copy.deepcopy(e)
+
+
 def _bits(v):
   return np.float64(v).view(np.uint64)
 
@@ -49,7 +58,7 @@ def test_oracle_equals_reference_environment(module, mode, capsys):
                               pos_is_f32=(lowering.position_dtype(episodes) == np.float32))
   pool = lowering.lower_episodes(episodes, task, rends, max_sprites=S).assign_round_robin(1)
   eng = oracle.Engine(cfg, pool)
-  it = iter([copy.deepcopy(episodes[0])] + [copy.deepcopy(e) for e in episodes] * 20)
+  it = _fresh_episodes(episodes)
   config = dict(config, init_sprites=lambda: next(it))
   config['renderers'] = dict(rends, success=ref_renderers.Success())
   env = environment.Environment(**config)
@@ -101,7 +110,7 @@ def test_float64_sprites_and_motion_cost():
     assert cfg.pos_is_f32 == 0
     pool = lowering.lower_episodes(episodes, task, rends, max_sprites=4).assign_round_robin(1)
     eng = oracle.Engine(cfg, pool)
-    it = iter([copy.deepcopy(episodes[0])] + [copy.deepcopy(e) for e in episodes] * 20)
+    it = _fresh_episodes(episodes)
     env = environment.Environment(task=task, action_space=aspace, renderers=rends,
                                   init_sprites=lambda: next(it), keep_in_frame=False, max_episode_length=15)
     arng = np.random.RandomState(9)
@@ -142,7 +151,7 @@ def test_float32_actions_match_reference(module, mode, motion_cost):
   assert cfg.action_is_f32 == 1
   pool = lowering.lower_episodes(episodes, task, rends, max_sprites=S).assign_round_robin(1)
   eng = oracle.Engine(cfg, pool)
-  it = iter([copy.deepcopy(episodes[0])] + [copy.deepcopy(e) for e in episodes] * 20)
+  it = _fresh_episodes(episodes)
   config = dict(config, init_sprites=lambda: next(it))
   config['renderers'] = dict(rends, success=ref_renderers.Success())
   env = environment.Environment(**config)
@@ -159,3 +168,55 @@ def test_float32_actions_match_reference(module, mode, motion_cost):
     st = eng.state()
     n = st['n_sprites'][0]
     assert np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
+
+
+@pytest.mark.parametrize('space', ['select', 'embodied'])
+def test_ragged_episodes_from_empty_to_sixteen_sprites(space):
+  """Episodes of 0, 1, ... 16 sprites (the engine's maximum), some without any target: empty scenes,
+  an Embodied agent that is alone, NaN rewards when no sprite passes the filter (tasks.py:140-142)."""
+  ref_harness.load_reference()
+  from spriteworld import action_spaces, environment, renderers, sprite, tasks
+  from spriteworld import factor_distributions as distribs
+  from oracle import oracle
+  from spriteworld_amd import lowering
+  rng = np.random.RandomState(17)
+
+  def gen(n):
+    return [sprite.Sprite(x=np.float32(rng.uniform(0.05, 0.95)), y=np.float32(rng.uniform(0.05, 0.95)),
+                          shape=str(rng.choice(['square', 'triangle', 'circle', 'star_4'])),
+                          scale=float(rng.choice([0.08, 0.15])), c0=np.float32(rng.uniform(0, 1)),
+                          c1=np.float32(0.8), c2=np.float32(1.0)) for _ in range(n)]
+
+  counts = [0, 1, 16, 0, 3, 2, 16, 1, 7, 0, 12, 5]
+  episodes = [gen(n) for n in counts]
+  task = tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.3), terminate_distance=0.2)
+  aspace = action_spaces.SelectMove(scale=0.4) if space == 'select' else action_spaces.Embodied(step_size=0.1)
+  rends = {'image': renderers.PILRenderer(image_size=(64, 64), anti_aliasing=5, color_to_rgb=renderers.color_maps.hsv_to_rgb),
+           'success': renderers.Success()}
+  if space == 'embodied':       # Embodied needs a body: the reference indexes sprites[-1] (action_spaces.py:195)
+    episodes = [e for e in episodes if e]
+  cfg = lowering.lower_config(task, aspace, rends, True, 6, 1, 16, pos_is_f32=True)
+  pool = lowering.lower_episodes(episodes, task, rends, max_sprites=16).assign_round_robin(1)
+  eng = oracle.Engine(cfg, pool)
+  it = _fresh_episodes(episodes)
+  env = environment.Environment(task=task, action_space=aspace, renderers=rends, init_sprites=lambda: next(it),
+                                max_episode_length=6)
+  arng = np.random.RandomState(3)
+  for t in range(90):
+    if space == 'select':
+      a = arng.uniform(0, 1, 4)
+      ts = env.step(a)
+    else:
+      a = np.array([arng.randint(0, 2), arng.randint(0, 4)])
+      ts = env.step([int(a[0]), int(a[1])])
+    out = eng.step(a[None])
+    assert int(ts.step_type) == int(out['step_type'][0]), t
+    r = np.nan if ts.reward is None else float(ts.reward)
+    assert (np.isnan(r) and np.isnan(out['reward'][0])) or _bits(r) == _bits(out['reward'][0]), (t, r, out['reward'][0])
+    assert bool(ts.observation['success']) == bool(out['success'][0]), t
+    st = eng.state()
+    pos = np.array([sp.position for sp in env._sprites], dtype=np.float64).reshape(-1, 2)
+    n = st['n_sprites'][0]
+    assert n == len(pos)
+    assert np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
+    assert np.array_equal(ts.observation['image'], out['obs'][0]), t
