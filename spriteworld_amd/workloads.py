@@ -80,6 +80,18 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
                                shape_names=('square', 'triangle', 'circle', 'star_5', 'spoke_4'),
                                scales=(0.1, 0.2, 0.4), angles=tuple(range(0, 360, 23)), xy_range=(0.0, 1.0))
     cfg = lowering.lower_config(task, aspace, rend, True, 12, num_envs, 4, True)
+  elif name in ('ragged_s16', 'ragged_s16_embodied'):
+    # episodes of 0..16 sprites (the engine's maximum), some without any target
+    task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.15)
+    aspace = (action_spaces.Embodied(step_size=0.1) if name.endswith('embodied')
+              else action_spaces.SelectMove(scale=0.4))
+    rend = _renderers(64, aa)
+    labels = [[int(i % 3 == 0)] for i in range(16)]
+    pool = synthetic.make_pool(rng, P, 16, [(0.0, 1.0)] * 16, labels,
+                               shape_names=('square', 'triangle', 'circle', 'star_4'), scales=(0.08, 0.15))
+    pool.n_sprites[:] = rng.integers(0, 17, size=P)
+    pool.n_sprites[:4] = (0, 16, 1, 0)
+    cfg = lowering.lower_config(task, aspace, rend, True, 8, num_envs, 16, True)
   elif name == 'embodied_s12':
     task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
     aspace = action_spaces.Embodied(step_size=0.05)

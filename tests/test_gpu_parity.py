@@ -84,6 +84,11 @@ def test_six_clusters_scalar_davies_bouldin_path():
   _run('cluster6_s12', 128, 25, 2)
 
 
+@pytest.mark.parametrize('name', ['ragged_s16', 'ragged_s16_embodied'])
+def test_ragged_sprite_counts_zero_to_sixteen(name):
+  _run(name, 128, 20, 5)
+
+
 def test_cluster_s5_aa1():
   _run('cluster_s5', 128, 10, 1)
 
