@@ -324,10 +324,12 @@ static void* scratch(scratch_t* s, size_t bytes) {
 }
 typedef struct { int in, out, ks; int32_t* b; int32_t* k; } coeff_cache_t;
 static __thread coeff_cache_t tl_coeff[4];
-static const coeff_cache_t* cached_coeffs(int in, int out) {
+/* `keep`: an entry the caller still uses (never evicted by this call). */
+static const coeff_cache_t* cached_coeffs(int in, int out, const coeff_cache_t* keep) {
   for (int i = 0; i < 4; ++i)
     if (tl_coeff[i].b && tl_coeff[i].in == in && tl_coeff[i].out == out) return &tl_coeff[i];
   static __thread int next = 0;
+  if (&tl_coeff[next] == keep) next = (next + 1) & 3;
   coeff_cache_t* c = &tl_coeff[next];
   next = (next + 1) & 3;
   free(c->b); free(c->k);
@@ -346,10 +348,10 @@ static uint8_t clip8(int in) {
 /* Resample.c ImagingResample: horizontal pass then vertical pass, uint8
  * intermediate, 3 bands.  src [Hc][Wc][3] -> dst [H][W][3]. */
 static void resample_lanczos(const uint8_t* src, int Wc, int Hc, uint8_t* dst, int W, int H) {
-  const coeff_cache_t* ch = cached_coeffs(Wc, W);
+  const coeff_cache_t* ch = cached_coeffs(Wc, W, NULL);
   const int ksh = ch->ks;
   const int32_t *bh = ch->b, *kh = ch->k;
-  const coeff_cache_t* cv = cached_coeffs(Hc, H);   /* may evict ch only if > 4 size pairs are live */
+  const coeff_cache_t* cv = cached_coeffs(Hc, H, ch);
   const int ksv = cv->ks;
   const int32_t *bv = cv->b, *kv = cv->k;
   uint8_t* tmp = (uint8_t*)scratch(&tl_tmp, (size_t)Hc * W * 3);

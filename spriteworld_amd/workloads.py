@@ -92,6 +92,68 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     pool.n_sprites[:] = rng.integers(0, 17, size=P)
     pool.n_sprites[:4] = (0, 16, 1, 0)
     cfg = lowering.lower_config(task, aspace, rend, True, 8, num_envs, 16, True)
+  elif name.startswith('fuzz_'):
+    # randomised configuration (seeded by the name): image geometry, anti-aliasing, sprite counts,
+    # shapes / scales / angles, task, action space, position dtype, velocities, background
+    frng = np.random.default_rng(int(name[len('fuzz_'):]) + 977)
+    w, h = (int(4 * frng.integers(4, 41)) for _ in range(2))
+    aa = int(frng.choice([1, 2, 3, 5]))
+    if aa * w > 640:
+      aa = max(1, 640 // w)
+    S = int(frng.integers(1, 11))
+    all_shapes = list(renderers.__dict__.get('_unused', ())) or ['triangle', 'square', 'pentagon', 'hexagon', 'octagon',
+                                                                 'circle', 'star_4', 'star_5', 'star_6', 'spoke_4',
+                                                                 'spoke_5', 'spoke_6']
+    shape_names = tuple(frng.choice(all_shapes, size=int(frng.integers(1, 6)), replace=False))
+    scales = tuple(float(v) for v in frng.choice([0.02, 0.05, 0.08, 0.13, 0.2, 0.35, 0.6], size=3))
+    angles = tuple(int(v) for v in frng.integers(0, 360, size=5)) + (0,)
+    kind = int(frng.integers(0, 4))
+    f32_pos = bool(frng.integers(0, 2))
+    embodied = bool(frng.integers(0, 3) == 0)
+    keep = bool(frng.integers(0, 2))
+    n_tasks = 1
+    if kind == 0 or S < 4:
+      task = tasks.FindGoalPosition(filter_distrib=None, goal_position=(float(frng.uniform(0.2, 0.8)), float(frng.uniform(0.2, 0.8))),
+                                    terminate_distance=float(frng.uniform(0.05, 0.3)), terminate_bonus=float(frng.integers(0, 3)),
+                                    weights_dimensions=(float(frng.integers(1, 3)), float(frng.integers(0, 3))),
+                                    sparse_reward=bool(frng.integers(0, 2)), raw_reward_multiplier=float(frng.integers(1, 60)))
+      labels = [[int(frng.integers(0, 2))] for _ in range(S)]
+    elif kind in (1, 2):
+      k = 2 if S < 6 else int(frng.integers(2, 4))
+      task = tasks.Clustering([None] * k, termination_threshold=float(frng.uniform(1.0, 3.0)),
+                              terminate_bonus=float(frng.integers(0, 2)), sparse_reward=bool(frng.integers(0, 2)),
+                              reward_range=float(frng.integers(1, 12)))
+      labels = [[c % k] for c in range(2 * k)] + [[int(frng.integers(-1, k))] for _ in range(S - 2 * k)]
+    else:
+      subs = [tasks.FindGoalPosition(filter_distrib=None, goal_position=(0.25 + 0.5 * (i % 2), 0.25 + 0.5 * (i // 2)),
+                                     terminate_distance=0.2, raw_reward_multiplier=10.) for i in range(3)]
+      task = tasks.MetaAggregated(subs, reward_aggregator=str(frng.choice(['sum', 'max', 'min', 'mean'])),
+                                  termination_criterion=str(frng.choice(['all', 'any'])), terminate_bonus=float(frng.integers(0, 2)))
+      labels = [[int(i % 3 == t) for t in range(3)] for i in range(S)]
+      n_tasks = 3
+    if embodied:
+      aspace = action_spaces.Embodied(step_size=float(frng.choice([0.05, 0.1])), motion_cost=float(frng.choice([0.0, 0.4])))
+    elif frng.integers(0, 2):
+      aspace = action_spaces.SelectMove(scale=float(frng.choice([0.25, 0.5])), motion_cost=float(frng.choice([0.0, 0.7])))
+    else:
+      aspace = action_spaces.DragAndDrop(scale=float(frng.choice([0.25, 0.5])), motion_cost=float(frng.choice([0.0, 1.3])))
+    rend = {'image': renderers.PILRenderer(image_size=(w, h), anti_aliasing=aa,
+                                           bg_color=tuple(int(v) for v in (frng.integers(0, 256, 3) * frng.integers(0, 2))),
+                                           color_to_rgb=renderers.hsv_to_rgb)}
+    pool = synthetic.make_pool(rng, P, S, [(0.0, 1.0)] * S, labels, n_tasks=n_tasks, shape_names=shape_names, scales=scales,
+                               angles=angles, xy_range=(-0.05, 1.05) if not keep else (0.0, 1.0))
+    if not f32_pos:
+      pool.x[:] = rng.uniform(0.0, 1.0, size=pool.x.shape)
+      pool.y[:] = rng.uniform(0.0, 1.0, size=pool.y.shape)
+    if frng.integers(0, 2):
+      vel = rng.uniform(-0.02, 0.02, size=(2,) + pool.x.shape)
+      if f32_pos:
+        vel = vel.astype(np.float32).astype(np.float64)
+      pool.x_vel[:], pool.y_vel[:] = vel[0], vel[1]
+    pool.n_sprites[:] = np.maximum(rng.integers(S // 2, S + 1, size=P), 1 if embodied else 0)
+    if kind in (1, 2) and S >= 4:
+      pool.n_sprites[:] = S            # keep Davies-Bouldin's label-count precondition (2 <= k < m)
+    cfg = lowering.lower_config(task, aspace, rend, keep, int(frng.integers(3, 15)), num_envs, S, f32_pos)
   elif name == 'embodied_s12':
     task = tasks.FindGoalPosition(filter_distrib=None, terminate_distance=0.075)
     aspace = action_spaces.Embodied(step_size=0.05)

@@ -121,3 +121,9 @@ def test_float32_actions(name, aa):
 def test_image_geometries(geom, aa):
   """Non-square and wide images: every kernel variant (canvas words x output columns x rows in flight)."""
   _run('geom_' + geom, 48, 6, aa)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_randomised_configurations(seed):
+  """Seeded random configurations: geometry x anti-aliasing x sprite counts x shapes x task x action space x dtype."""
+  _run('fuzz_%d' % seed, 64, 10, 5, seed=seed)
