@@ -220,3 +220,119 @@ def test_ragged_episodes_from_empty_to_sixteen_sprites(space):
     assert n == len(pos)
     assert np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
     assert np.array_equal(ts.observation['image'], out['obs'][0]), t
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_randomised_reference_configurations(seed):
+  """Seeded random environments built from the reference's own classes (non-square images, any
+  anti-aliasing, all shapes, rotations, float32 / float64 sprites, velocities, every task and action
+  space, with and without keep_in_frame) against the oracle, step for step."""
+  ref_harness.load_reference()
+  from spriteworld import action_spaces, environment, renderers, sprite, tasks
+  from spriteworld import constants
+  from spriteworld import factor_distributions as distribs
+  from oracle import oracle
+  from spriteworld_amd import lowering
+  rng = np.random.RandomState(1000 + seed)
+  w, h = (int(4 * rng.randint(4, 30)) for _ in range(2))
+  aa = int(rng.choice([1, 2, 3, 5]))
+  S = int(rng.randint(1, 9))
+  shapes_ = list(rng.choice(sorted(constants.SHAPES), size=int(rng.randint(1, 5)), replace=False))
+  f32 = bool(rng.randint(0, 2))
+  hsv = bool(rng.randint(0, 2))
+  keep = bool(rng.randint(0, 2))
+  vel = bool(rng.randint(0, 2))
+
+  def num(lo, hi):
+    v = rng.uniform(lo, hi)
+    return np.float32(v) if f32 else float(v)
+
+  def gen(n):
+    out = []
+    for _ in range(n):
+      color = (num(0, 1), num(0.3, 1), num(0.5, 1)) if hsv else tuple(int(c) for c in rng.randint(0, 256, 3))
+      out.append(sprite.Sprite(x=num(-0.05, 1.05) if not keep else num(0, 1), y=num(0, 1),
+                               shape=str(rng.choice(shapes_)), angle=int(rng.randint(0, 360)) if rng.randint(0, 2) else 0,
+                               scale=float(rng.choice([0.03, 0.08, 0.13, 0.25, 0.5])),
+                               c0=color[0], c1=color[1], c2=color[2],
+                               x_vel=float(rng.uniform(-0.02, 0.02)) if vel else 0.0,
+                               y_vel=float(rng.uniform(-0.02, 0.02)) if vel else 0.0))
+    return out
+
+  kind = int(rng.randint(0, 3)) if S >= 4 else 0
+  if kind == 0:
+    key = 'c0'
+    thr = 0.5 if hsv else 128
+    filt = distribs.Continuous(key, 0, thr) if rng.randint(0, 2) else None
+    task = tasks.FindGoalPosition(filter_distrib=filt, goal_position=(rng.uniform(0.2, 0.8), rng.uniform(0.2, 0.8)),
+                                  terminate_distance=float(rng.uniform(0.05, 0.4)), terminate_bonus=float(rng.randint(0, 3)),
+                                  sparse_reward=bool(rng.randint(0, 2)), raw_reward_multiplier=float(rng.randint(1, 60)))
+  elif kind == 1:
+    thr = 0.5 if hsv else 128
+    top = 1.0 if hsv else 256
+    task = tasks.Clustering([distribs.Continuous('c0', 0, thr), distribs.Continuous('c0', thr, top)],
+                            termination_threshold=float(rng.uniform(1.0, 3.0)), terminate_bonus=float(rng.randint(0, 2)),
+                            sparse_reward=bool(rng.randint(0, 2)), reward_range=float(rng.randint(1, 12)))
+  else:
+    thr = 0.5 if hsv else 128
+    top = 1.0 if hsv else 256
+    subs = [tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0, thr), goal_position=(0.25, 0.75), terminate_distance=0.3),
+            tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', thr, top), goal_position=(0.75, 0.25), terminate_distance=0.3)]
+    task = tasks.MetaAggregated(subs, reward_aggregator=str(rng.choice(['sum', 'max', 'min', 'mean'])),
+                                termination_criterion=str(rng.choice(['all', 'any'])), terminate_bonus=float(rng.randint(0, 2)))
+  which = int(rng.randint(0, 3))
+  aspace = [action_spaces.SelectMove(scale=0.4, motion_cost=float(rng.choice([0.0, 0.7]))),
+            action_spaces.DragAndDrop(scale=0.5, motion_cost=float(rng.choice([0.0, 1.3]))),
+            action_spaces.Embodied(step_size=0.1, motion_cost=float(rng.choice([0.0, 0.4])))][which]
+  rends = {'image': renderers.PILRenderer(image_size=(w, h), anti_aliasing=aa,
+                                          bg_color=tuple(int(c) for c in rng.randint(0, 256, 3)) if rng.randint(0, 2) else None,
+                                          color_to_rgb=renderers.color_maps.hsv_to_rgb if hsv else None),
+           'success': renderers.Success()}
+
+  def valid(ep):     # Clustering needs every cluster populated and more sprites than clusters
+    if kind != 1:
+      return True
+    thr_ = 0.5 if hsv else 128
+    lo = sum(1 for sp in ep if sp.c0 < thr_)
+    return 1 <= lo < len(ep) and len(ep) > 2
+  episodes = []
+  while len(episodes) < 8:
+    ep = gen(S if kind else int(rng.randint(max(1, S // 2), S + 1)))
+    if valid(ep):
+      episodes.append(ep)
+  max_len = int(rng.randint(3, 12))
+  cfg = lowering.lower_config(task, aspace, rends, keep, max_len, 1, S,
+                              pos_is_f32=(lowering.position_dtype(episodes) == np.float32))
+  pool = lowering.lower_episodes(episodes, task, rends, max_sprites=S).assign_round_robin(1)
+  eng = oracle.Engine(cfg, pool)
+  it = _fresh_episodes(episodes)
+  env = environment.Environment(task=task, action_space=aspace, renderers=rends, init_sprites=lambda: next(it),
+                                keep_in_frame=keep, max_episode_length=max_len)
+  arng = np.random.RandomState(seed)
+  for t in range(60):
+    if which == 2:
+      a = np.array([arng.randint(0, 2), arng.randint(0, 4)])
+      try:
+        ts = env.step([int(a[0]), int(a[1])])
+      except ZeroDivisionError:
+        assert eng.step(a[None])['error'][0] & 1
+        return
+    else:
+      a = arng.uniform(0, 1, 4)
+      try:
+        ts = env.step(a)
+      except ZeroDivisionError:
+        assert eng.step(a[None])['error'][0] & 1
+        return
+    out = eng.step(a[None])
+    assert not out['error'][0], t
+    assert int(ts.step_type) == int(out['step_type'][0]), t
+    r = np.nan if ts.reward is None else float(ts.reward)
+    assert (np.isnan(r) and np.isnan(out['reward'][0])) or _bits(r) == _bits(out['reward'][0]), (t, r, out['reward'][0])
+    assert bool(ts.observation['success']) == bool(out['success'][0]), t
+    st = eng.state()
+    pos = np.array([sp.position for sp in env._sprites], dtype=np.float64).reshape(-1, 2)
+    n = st['n_sprites'][0]
+    assert n == len(pos)
+    assert np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
+    assert np.array_equal(ts.observation['image'], out['obs'][0]), t
