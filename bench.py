@@ -83,6 +83,37 @@ def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
   return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, a_bytes=a_bytes, errors=errors)
 
 
+def gpu_run_groups(name, n_envs, groups, steps, warmup, aa, device):
+  """The same batch as `groups` independent engines stepped on `groups` HIP streams (no cross-group
+  ordering between steps): the double-buffered stepping pattern of RL samplers.  Returns env-steps/s."""
+  import torch
+  from spriteworld_amd import engine, workloads
+  n = n_envs // groups
+  engs, acts, streams = [], [], []
+  for g in range(groups):
+    cfg, pool, sample = workloads.build(name, n, episodes_per_env=4, seed=g, anti_aliasing=aa)
+    engs.append(engine.Engine(cfg, pool, device=device))
+    rng = np.random.default_rng(2000 + g)
+    acts.append([torch.as_tensor(sample(rng), device=engs[g].device) for _ in range(N_ACTION_SETS)])
+    streams.append(torch.cuda.Stream(device=engs[g].device))
+
+  def run(k):
+    for i in range(k):
+      for g in range(groups):
+        with torch.cuda.stream(streams[g]):
+          engs[g].step(acts[g][i % N_ACTION_SETS])
+  run(warmup)
+  torch.cuda.synchronize(engs[0].device)
+  t0 = time.perf_counter()
+  run(steps)
+  torch.cuda.synchronize(engs[0].device)
+  elapsed = time.perf_counter() - t0
+  errors = max(int(e.error.max().item()) for e in engs)
+  for e in engs:
+    e.close()
+  return n * groups * steps / elapsed, errors
+
+
 def usable_cores():
   """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
   try:
@@ -164,8 +195,16 @@ def main():
   if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:   # launched by torch.distributed.run
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    # SWB_BENCH_ONE_DEVICE=1: functional check of the N > 1 path on a 1-GPU box (all ranks on cuda:0, gloo
+    # instead of RCCL, which refuses two ranks on one device); never set by the driver
+    one_device = os.environ.get('SWB_BENCH_ONE_DEVICE') == '1'
+    if one_device:
+      local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if one_device:
+      dist.init_process_group('gloo')
+    else:
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     barrier = dist.barrier
   device = local_rank if dist is not None else 0
 
@@ -173,7 +212,7 @@ def main():
                 barrier=barrier, seed=rank)
   elapsed = res['elapsed']
   if dist is not None:
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else 'cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -237,6 +276,10 @@ def main():
       ks = r['kernel_ms'] / 1e3 / max(r['launches'], 1)
       extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel_ms': ks * 1e3,
                       'hbm_GBs': r['a_bytes'] * n / ks / 1e9, 'env_errors': r['errors']}
+    # the headline batch as two groups of 4096 on two HIP streams: consecutive steps of different groups overlap,
+    # which hides the fill/drain of each launch (an application-level choice; `value` above is one launch per step)
+    rate, errs = gpu_run_groups(args.workload, args.envs_per_gpu, 2, short, 5, args.aa, device)
+    extra['%s_2_groups_2_streams' % args.workload] = {'env_steps_per_s': rate, 'env_errors': errs}
     out['extra'] = extra
   if args.gpus == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(args.workload, args.aa)

@@ -174,3 +174,34 @@ def test_sprite_factors_observation_and_action_noise():
   hit = moved != 0                      # a noised click may miss the sprite
   assert hit.sum() >= 8 and np.all(np.abs(moved[hit] - 0.1) < 0.1) and np.std(moved[hit]) > 1e-3
   env.close()
+
+
+@pytest.mark.gpu
+def test_environment_groups_equal_the_groups_stepped_alone():
+  """EnvironmentGroups: per-group streams change the schedule, not the results."""
+  import torch
+  from spriteworld_amd import environment
+  config = _cobra_like_config()
+  np.random.seed(11)
+  groups = environment.EnvironmentGroups(num_groups=2, num_envs=64, **config)
+  np.random.seed(11)
+  alone = [environment.BatchedEnvironment(num_envs=32, **config) for _ in range(2)]
+  gen = torch.Generator().manual_seed(4)
+  for g in range(2):
+    a, b = groups.reset(g), alone[g].reset()
+    groups.synchronize()
+    assert torch.equal(a.observation['image'], b.observation['image'])
+  for _ in range(12):
+    acts = [torch.rand((32, 4), generator=gen, dtype=torch.float64).cuda() for _ in range(2)]
+    torch.cuda.synchronize()
+    outs = [groups.step(g, acts[g]) for g in range(2)]
+    groups.synchronize()
+    for g in range(2):
+      ref = alone[g].step(acts[g])
+      torch.cuda.synchronize()
+      assert torch.equal(outs[g].observation['image'], ref.observation['image'])
+      np.testing.assert_array_equal(outs[g].reward.cpu().numpy(), ref.reward.cpu().numpy())
+      assert torch.equal(outs[g].step_type, ref.step_type)
+  groups.close()
+  for e in alone:
+    e.close()
