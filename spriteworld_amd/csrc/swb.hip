@@ -5,6 +5,7 @@
 // Built only for gfx950:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,9 +59,10 @@ struct swb_engine {
   size_t lds_block = 0;
   // owned device buffers
   double* d_shape_verts = nullptr;
+  double* d_shape_dmin = nullptr;
   int32_t* d_shape_off = nullptr;
   int32_t *d_h_xmin = nullptr, *d_h_cnt = nullptr, *d_h_tbl = nullptr, *d_h_pfx = nullptr;
-  int32_t *d_v_tab = nullptr, *d_v_end = nullptr;
+  int32_t *d_v_tab = nullptr, *d_v_end = nullptr, *d_v_pfx = nullptr;
   int32_t* d_p_n = nullptr;
   double *d_p_x = nullptr, *d_p_y = nullptr, *d_p_xv = nullptr, *d_p_yv = nullptr, *d_p_scale = nullptr,
          *d_p_ca = nullptr, *d_p_sa = nullptr;
@@ -131,7 +133,10 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   const variant* v = pick_variant(h->p.Wc, h->p.Wo, h->vslots);
   if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d / image width %d not supported", h->p.Wc, h->p.Hc, h->p.Wo);
   swb_params p = h->p;
-  if (p.v_tab && v->vs == 8) p.v_tab += (size_t)p.Hc * SWB_VSLOTS;   // slot table of this variant's VS
+  if (p.v_tab && v->vs == 8) {                                        // slot tables of this variant's VS
+    p.v_tab += (size_t)p.Hc * SWB_VSLOTS;
+    p.v_pfx += (size_t)(p.Hc + 1) * SWB_VSLOTS;
+  }
   p.actions = actions;
   p.obs = out ? out->obs : nullptr;
   p.reward = out ? out->reward : nullptr;
@@ -242,8 +247,8 @@ int swb_destroy(swb_handle h) {
   if (!h) return SWB_OK;
   (void)hipSetDevice(h->device);
   for (auto& ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  void* bufs[] = {h->d_shape_verts, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
-                  h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
+  void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
+                  h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
                   h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_p_angle, h->d_p_color, h->d_sampler};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -261,6 +266,18 @@ int swb_upload_shapes(swb_handle h, const double* verts, const int32_t* offsets,
     if (n < 3 || n > SWB_MAX_SHAPE_VERTS) return fail(SWB_ERR_INVALID, "shape %d has %d vertices (3..%d supported)", i, n, SWB_MAX_SHAPE_VERTS);
     if (n > maxv) maxv = n;
   }
+  // smallest distance between two vertices of each shape: the kernel's test for "no two vertices
+  // of this sprite can land on one canvas pixel" (swb_kernels.hip.inc, build_all_edges)
+  std::vector<double> dmin(n_shapes, 0.0);
+  for (int i = 0; i < n_shapes; ++i) {
+    double best = 1e300;
+    for (int a = offsets[i]; a < offsets[i + 1]; ++a)
+      for (int b = a + 1; b < offsets[i + 1]; ++b)
+        best = std::min(best, std::hypot(verts[2 * a] - verts[2 * b], verts[2 * a + 1] - verts[2 * b + 1]));
+    dmin[i] = best;
+  }
+  if (upload(&h->d_shape_dmin, dmin.data(), (size_t)n_shapes)) return SWB_ERR_HIP;
+  h->p.shape_dmin = h->d_shape_dmin;
   if (upload(&h->d_shape_verts, verts, (size_t)offsets[n_shapes] * 2)) return SWB_ERR_HIP;
   if (upload(&h->d_shape_off, offsets, (size_t)n_shapes + 1)) return SWB_ERR_HIP;
   h->p.shape_verts = h->d_shape_verts;
@@ -328,8 +345,19 @@ int swb_upload_resample(swb_handle h, int32_t axis, int32_t out_size, int32_t ks
         if (k + 1 > used) used = k + 1;
       }
     }
-    if (upload(&h->d_v_tab, vtab.data(), vtab.size()) || upload(&h->d_v_end, vend.data(), vend.size())) return SWB_ERR_HIP;
-    h->p.v_tab = h->d_v_tab; h->p.v_end = h->d_v_end;
+    // prefix sums over canvas rows of both slot tables: the coefficient sums of a run of rows
+    // [y1, y2] that lies between two row completions are pfx[y2 + 1] - pfx[y1]
+    const size_t pfx_len = (size_t)(p.Hc + 1) * SWB_VSLOTS;
+    std::vector<int32_t> vpfx(2 * pfx_len, 0);
+    for (int t = 0; t < 2; ++t)
+      for (int y = 0; y < p.Hc; ++y)
+        for (int k = 0; k < SWB_VSLOTS; ++k)
+          vpfx[t * pfx_len + (size_t)(y + 1) * SWB_VSLOTS + k] =
+              vpfx[t * pfx_len + (size_t)y * SWB_VSLOTS + k] + vtab[t * tab_len + (size_t)y * SWB_VSLOTS + k];
+    if (upload(&h->d_v_tab, vtab.data(), vtab.size()) || upload(&h->d_v_end, vend.data(), vend.size()) ||
+        upload(&h->d_v_pfx, vpfx.data(), vpfx.size()))
+      return SWB_ERR_HIP;
+    h->p.v_tab = h->d_v_tab; h->p.v_end = h->d_v_end; h->p.v_pfx = h->d_v_pfx;
     h->vslots = used;
     h->have_v = true;
   } else {
