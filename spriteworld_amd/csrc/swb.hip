@@ -89,11 +89,13 @@ namespace {
 
 typedef void (*kernel_fn)(const swb_params);
 
-struct variant { int nw, ncol, vs; kernel_fn fn; size_t lds_fixed; };
+struct variant { int nw, ncol, vs; kernel_fn fn; size_t lds_fixed, outrow_bytes; };
 
 template <int NW, int NCOL, int VS>
 variant make_variant() {
-  return {NW, NCOL, VS, swb_step_kernel<NW, NCOL, VS>, (sizeof(wave_lds<NW>) + 15) & ~(size_t)15};
+  // wave_lds<NW> + the output-row staging (3 bytes per pixel; never less than build_all_edges' 98 dwords of scratch)
+  const size_t outrow = std::max<size_t>(392, (size_t)NCOL * 64 * 3);
+  return {NW, NCOL, VS, swb_step_kernel<NW, NCOL, VS>, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
 }
 
 // canvas widths up to 32*NW pixels, image widths up to 64*NCOL pixels, up to VS output rows in
@@ -153,6 +155,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   const size_t per_wave = (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
                            (size_t)p.max_spans * SWB_WAVE * 4 + (p.cpath_in_masks ? 0 : cpath_bytes) + 15) & ~(size_t)15;
   p.lds_per_wave = (int32_t)per_wave;
+  p.outrow_bytes = (int32_t)v->outrow_bytes;
   const size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
   if (lds > 64 * 1024)
@@ -231,8 +234,8 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   if (rc) { swb_destroy(h); return SWB_ERR_HIP; }
   // visible-span lists: M per canvas row in LDS, the (never expected) rest in HBM; a row of Wc
   // pixels has at most Wc/2 + 1 runs, so M + ovf_cap >= that bound makes overflow impossible.
-  p.max_spans = 6;
-  if (const char* ms = getenv("SWB_MAX_SPANS")) p.max_spans = atoi(ms) < 6 ? 6 : atoi(ms);
+  p.max_spans = SWB_MIN_SPANS;
+  if (const char* ms = getenv("SWB_MAX_SPANS")) p.max_spans = atoi(ms) < SWB_MIN_SPANS ? SWB_MIN_SPANS : atoi(ms);
   p.ovf_cap = p.Wc / 2 + 1;
   rc |= upload(&h->d_ovf, (const uint32_t*)nullptr, (size_t)p.N * 64 * p.ovf_cap);
   if (rc) { swb_destroy(h); return SWB_ERR_HIP; }

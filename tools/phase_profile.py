@@ -25,6 +25,11 @@ PHASE_NAMES = {3: 'loads + centred paths', 4: '+ action/hit-test/move', 5: '+ ta
 WORKLOADS = (('cluster_s5', 5), ('cluster_s5', 1), ('goal_s5', 5), ('embodied_s12', 5))
 N_ENVS = 8192
 PMC_LAUNCHES = 12
+# PHASE_WORKLOADS="cluster_s5:5,goal_s5:5" PHASE_LIST="2,0" restrict a run (same values for pmc-run and pmc-report)
+if os.environ.get('PHASE_WORKLOADS'):
+  WORKLOADS = tuple((w.split(':')[0], int(w.split(':')[1])) for w in os.environ['PHASE_WORKLOADS'].split(','))
+if os.environ.get('PHASE_LIST'):
+  PHASES = tuple(int(v) for v in os.environ['PHASE_LIST'].split(','))
 
 
 def run(name, aa, phase, steps, warmup, timing):
