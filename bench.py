@@ -14,8 +14,12 @@ Clustering reward, 64x64 PILRenderer with anti_aliasing=5 (the COBRA renderer), 
 
 roofline:     algorithmic bytes per launch (12 461 B/env-step) / the fused
               kernel's mean duration measured with HIP events on the launch stream, vs 8 TB/s HBM.
+              `kernel`, `metric` and `config` are derived from what ran (swb_variant / the lowered
+              config), `traffic` and `instructions` come from the committed PMC passes of exactly
+              this build (profiles/r02_counters.json, keyed by the library's build id) or are null.
 cpu_baseline: the CPU oracle (a C port of the reference algorithm, oracle/sw_oracle.c) stepping a
-              bounded sample of the same workload on all host cores of rank 0.
+              bounded sample of the same workload on all host cores of rank 0, with the survey's
+              rate of the unmodified Python reference beside it.
 """
 import argparse
 import json
@@ -41,16 +45,28 @@ def algorithmic_bytes(cfg):
   return 3 * cfg.image_h * cfg.image_w + 28 * cfg.max_sprites + 17 + action_bytes
 
 
-def measured_traffic(args):
-  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None.
+# Survey-time rate of the unmodified reference (Python + PIL + sklearn) on one host core, BASELINE.md section 2.
+# /root/reference does not exist on the GPU box, so the same-run CPU baseline is the C port (oracle/sw_oracle.c),
+# which is 3-9x faster per core than the reference; both figures are put in the line.
+REFERENCE_RATE_PER_CORE = {'cluster_s5': 228.0, 'goal_s5': 637.0, 'embodied_s12': 156.0}
+VALU_CYCLES_PER_INST = 4.24      # profiles/r02_ubench_valu.md + SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the step kernel
 
-  bench.py cannot collect PMC counters itself; the figure is the one measured for this round's
-  kernel on the default workload (see profiles/r01_traffic.json for the passes and corrections)."""
-  path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-  if args.workload != WORKLOAD or args.envs_per_gpu != ENVS_PER_GPU or args.aa != 5 or not os.path.exists(path):
+
+def profiled_counters(workload, envs, aa, build_id):
+  """PMC figures of the committed rocprofv3 passes (profiles/r02_counters.json) for this exact build and workload.
+
+  bench.py cannot collect PMC counters itself.  The file records the build id (content hash of the kernel sources)
+  the passes ran on; for any other build, workload or batch the figures are stale and None is returned."""
+  path = os.path.join(ROOT, 'profiles', 'r02_counters.json')
+  if not os.path.exists(path):
     return None
   with open(path) as f:
-    return json.load(f)['traffic_bytes_per_launch']
+    data = json.load(f)
+  for rec in data.get('records', []):
+    if (rec['build_id'] == build_id and rec['workload'] == workload and rec['envs'] == envs and
+        rec['anti_aliasing'] == aa):
+      return rec
+  return None
 
 
 def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
@@ -79,8 +95,14 @@ def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
   eng.timing(False)
   errors = int(eng.error.max().item())
   a_bytes = algorithmic_bytes(cfg)
+  variant = eng.variant()
+  facts = dict(sprites=cfg.max_sprites, image=[cfg.image_w, cfg.image_h], anti_aliasing=cfg.anti_aliasing,
+               action_space={0: 'SelectMove', 1: 'DragAndDrop', 2: 'Embodied'}[cfg.action_space],
+               task={0: 'NoReward', 1: 'FindGoalPosition', 2: 'Clustering'}[cfg.tasks[0].kind] if not cfg.is_meta
+               else 'MetaAggregated', max_episode_length=cfg.max_episode_length)
   eng.close()
-  return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, a_bytes=a_bytes, errors=errors)
+  return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, a_bytes=a_bytes, errors=errors,
+              variant=variant, facts=facts)
 
 
 def gpu_run_groups(name, n_envs, groups, steps, warmup, aa, device):
@@ -163,9 +185,15 @@ def cpu_baseline(name, aa, budget_s=12.0):
       one_step(sample(rng))
       steps += 1
     dt = time.perf_counter() - t0
-  return dict(value=n_envs * steps / dt, unit='env-steps/s', cores=cores, kind='port',
-              sample='%d envs x %d steps of %s (AA=%d) with oracle/sw_oracle.c on %d threads, %.1f s' %
-              (n_envs, steps, name, aa, cores, dt))
+  out = dict(value=n_envs * steps / dt, unit='env-steps/s', cores=cores, kind='port',
+             sample='%d envs x %d steps of %s (AA=%d) with oracle/sw_oracle.c on %d threads, %.1f s' %
+             (n_envs, steps, name, aa, cores, dt))
+  if name in REFERENCE_RATE_PER_CORE and aa == 5:
+    out['reference_env_steps_per_s_per_core'] = REFERENCE_RATE_PER_CORE[name]
+    out['reference_note'] = ('the unmodified Python reference measured %.0f env-steps/s on one core for this config '
+                             '(BASELINE.md section 2, survey container); it cannot run on the GPU box, so the timed '
+                             'baseline here is its C port' % REFERENCE_RATE_PER_CORE[name])
+  return out
 
 
 def main():
@@ -231,8 +259,32 @@ def main():
   value = total_envs * args.steps / elapsed
   kernel_s = res['kernel_ms'] / 1e3 / max(res['launches'], 1)
   achieved = res['a_bytes'] * args.envs_per_gpu / kernel_s / 1e9
+  facts, variant = res['facts'], res['variant']
+  image = '%dx%d' % (facts['image'][1], facts['image'][0])
+  counters = profiled_counters(args.workload, args.envs_per_gpu, args.aa, variant['build_id'])
+  roofline = {
+      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+      'frac': achieved / HBM_PEAK_GBS, 'frac_of_measured_copy_peak': achieved / 6290.0,
+      'traffic': counters['hbm_traffic_bytes_per_launch'] if counters else None,
+      'kernel': variant['kernel'], 'kernel_ms': kernel_s * 1e3,
+      'algorithmic_bytes_per_env_step': res['a_bytes'],
+      'lds_bytes_per_wave': variant['lds_bytes_per_wave'], 'waves_per_simd': variant['waves_per_simd'],
+      'build_id': variant['build_id'],
+  }
+  if counters:
+    # instruction side (SURVEY 8d asks for both): the kernel is bound by instruction issue, not by HBM
+    waves_per_simd_resident = counters.get('resident_waves_per_simd', variant['waves_per_simd'])
+    roofline['instructions'] = {
+        'insts_valu_per_wave': counters['insts_valu_per_wave'], 'insts_salu_per_wave': counters['insts_salu_per_wave'],
+        'insts_lds_per_wave': counters['insts_lds_per_wave'],
+        'valu_cycles_per_inst': VALU_CYCLES_PER_INST,
+        'valu_issue_frac': counters['active_inst_valu_per_wave'] * waves_per_simd_resident / counters['wave_cycles_per_wave'],
+        'source': counters['source'],
+    }
+  else:
+    roofline['instructions'] = None       # no committed PMC pass for this build / workload (see profiles/)
   out = {
-      'metric': 'env-steps/sec (incl. 64x64 RGB render) at 8192 envs',
+      'metric': 'env-steps/sec (incl. %s RGB render) at %d envs' % (image, args.envs_per_gpu),
       'value': value,
       'unit': 'env-steps/s',
       'n_gpus': args.gpus,
@@ -245,18 +297,16 @@ def main():
       'dtype': 'i32 fixed-point raster/resample + f64 state',
       'data': 'synthetic',
       'config': {
-          'workload': 'BASELINE configs[2]: %d envs/GPU x 5 sprites, SelectMove(0.25), Clustering reward, '
-                      '64x64 PILRenderer anti_aliasing=%d, auto-reset from an HBM pool' %
-                      (args.envs_per_gpu, args.aa),
-          'envs_per_gpu': args.envs_per_gpu, 'sprites': 5, 'image': [64, 64], 'anti_aliasing': args.aa,
+          'workload': '%s: %d envs/GPU x %d sprites, %s, %s reward, %s PILRenderer anti_aliasing=%d, auto-reset from '
+                      'an HBM pool%s' % (args.workload, args.envs_per_gpu, facts['sprites'], facts['action_space'],
+                                         facts['task'], image, facts['anti_aliasing'],
+                                         ' (BASELINE configs[2])' if (args.workload, args.envs_per_gpu, args.aa) ==
+                                         (WORKLOAD, ENVS_PER_GPU, 5) else ''),
+          'envs_per_gpu': args.envs_per_gpu, 'sprites': facts['sprites'], 'image': facts['image'],
+          'anti_aliasing': facts['anti_aliasing'],
           'parallelism': 'env-sharded x%d, no data-path collective' % args.gpus,
       },
-      'roofline': {
-          'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-          'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(args),
-          'kernel': 'swb_step_kernel<10,1,6>', 'kernel_ms': kernel_s * 1e3,
-          'algorithmic_bytes_per_env_step': res['a_bytes'],
-      },
+      'roofline': roofline,
       'env_errors': res['errors'],
   }
   if gather is not None:
@@ -274,8 +324,9 @@ def main():
     }.items():
       r = gpu_run(nm, n, short, 5, aa, device)
       ks = r['kernel_ms'] / 1e3 / max(r['launches'], 1)
-      extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel_ms': ks * 1e3,
-                      'hbm_GBs': r['a_bytes'] * n / ks / 1e9, 'env_errors': r['errors']}
+      extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel': r['variant']['kernel'], 'kernel_ms': ks * 1e3,
+                      'hbm_GBs': r['a_bytes'] * n / ks / 1e9, 'hbm_frac': r['a_bytes'] * n / ks / 1e9 / HBM_PEAK_GBS,
+                      'env_errors': r['errors']}
     # the headline batch as two groups of 4096 on two HIP streams: consecutive steps of different groups overlap,
     # which hides the fill/drain of each launch (an application-level choice; `value` above is one launch per step)
     rate, errs = gpu_run_groups(args.workload, args.envs_per_gpu, 2, short, 5, args.aa, device)

@@ -69,7 +69,10 @@ enum swb_meta_termination { SWB_TERM_ALL = 0, SWB_TERM_ANY = 1 };
 /* dm_env.StepType values (environment.py:78,105-108). */
 enum swb_step_type { SWB_STEP_FIRST = 0, SWB_STEP_MID = 1, SWB_STEP_LAST = 2 };
 
-/* Per-environment error bits written to swb_outputs.error. */
+/* Per-environment error bits.  swb_outputs.error is STICKY: a step ORs its bits into the buffer and
+ * never clears it, so a caller that polls every k steps misses nothing; the caller zeroes the buffer
+ * after reading it.  (Where the reference raises -- Davies-Bouldin ValueError / ZeroDivisionError --
+ * the reward of that step is NaN and success is 0.) */
 enum swb_env_error {
   SWB_ENV_OK = 0,
   SWB_ENV_ERR_DB_ZERO = 1,       /* Davies-Bouldin score 0 => reference raises ZeroDivisionError (tasks.py:215) */
@@ -94,9 +97,9 @@ typedef struct swb_task {
 typedef struct swb_config {
   int32_t n_envs;             /* N                                                    */
   int32_t max_sprites;        /* S <= SWB_MAX_SPRITES (per-episode count may be less) */
-  int32_t image_h;            /* PILRenderer image_size[0]                            */
+  int32_t image_h;            /* PILRenderer image_size[0]: a multiple of 4, <= 256   */
   int32_t image_w;            /* PILRenderer image_size[1]                            */
-  int32_t anti_aliasing;      /* PILRenderer anti_aliasing (1..5)                     */
+  int32_t anti_aliasing;      /* PILRenderer anti_aliasing (>= 1; canvas width AA*image_size[0] <= 1023) */
   uint8_t bg_rgb[4];          /* PILRenderer bg_color (4th byte unused)               */
   int32_t action_space;       /* swb_action_space                                     */
   double action_scale;        /* SelectMove/DragAndDrop _scale ; Embodied _step_size  */
@@ -285,6 +288,19 @@ int swb_factors(swb_handle h, double* factors_dev, void* stream);
 /* Blocking state access (synchronises `stream`). */
 int swb_get_state(swb_handle h, const swb_state* host_state, void* stream);
 int swb_set_positions(swb_handle h, const double* x_host, const double* y_host, void* stream);
+
+/* Which build of the fused step kernel swb_step launches for this handle -- the template parameters
+ * of swb_step_kernel<NW, NCOL, VS> (32-pixel canvas words per row, output columns per lane, output
+ * rows in flight in the vertical pass) and its LDS footprint -- so that measurement code labels a
+ * run by what actually ran.  swb_build_id(): content hash of the sources and flags the library was
+ * built from (spriteworld_amd/build.py), "unknown" for a hand build. */
+typedef struct swb_variant_info {
+  int32_t nw, ncol, vs;
+  int32_t lds_bytes_per_wave;
+  int32_t waves_per_simd;     /* register budget the kernel was compiled for */
+} swb_variant_info;
+int swb_variant(swb_handle h, swb_variant_info* out);
+const char* swb_build_id(void);
 
 /* Kernel timing: HIP events recorded on `stream` around every swb_step launch
  * while enabled; swb_step_time_ms returns (total ms, launches) since enable. */

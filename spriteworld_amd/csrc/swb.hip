@@ -112,6 +112,17 @@ const variant* pick_variant(int Wc, int Wo, int vslots = SWB_VSLOTS) {
   return nullptr;
 }
 
+// LDS bytes of one wave (= one environment) of variant v: wave_lds + edge records + span lists
+// (+ the centred paths, 16 B per vertex, when the idle mask arrays are too small to hold them).
+size_t lds_per_wave(const swb_engine* h, const variant* v, int* cpath_in_masks) {
+  const swb_params& p = h->p;
+  const size_t cpath_bytes = (size_t)p.max_edges * 16;
+  const int in_masks = (2 * (size_t)SWB_NWA(v->nw) * SWB_WAVE * 4 >= cpath_bytes) ? 1 : 0;
+  if (cpath_in_masks) *cpath_in_masks = in_masks;
+  return (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
+          (size_t)p.max_spans * SWB_WAVE * 4 + (in_masks ? 0 : cpath_bytes) + 15) & ~(size_t)15;
+}
+
 int flush_timing(swb_engine* h) {
   for (auto& ev : h->events) {
     HIP_TRY(hipEventSynchronize(ev.second));
@@ -149,11 +160,9 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   p.render_only = render_only;
   if (!render_only && actions == nullptr) return fail(SWB_ERR_INVALID, "actions is NULL");
   const size_t pfx_bytes = ((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15;
-  // centred paths (16 B per vertex): inside the mask arrays when they are large enough
-  const size_t cpath_bytes = (size_t)p.max_edges * 16;
-  p.cpath_in_masks = (2 * (size_t)SWB_NWA(v->nw) * SWB_WAVE * 4 >= cpath_bytes) ? 1 : 0;
-  const size_t per_wave = (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
-                           (size_t)p.max_spans * SWB_WAVE * 4 + (p.cpath_in_masks ? 0 : cpath_bytes) + 15) & ~(size_t)15;
+  int cpath_in_masks = 0;
+  const size_t per_wave = lds_per_wave(h, v, &cpath_in_masks);
+  p.cpath_in_masks = cpath_in_masks;
   p.lds_per_wave = (int32_t)per_wave;
   p.outrow_bytes = (int32_t)v->outrow_bytes;
   const size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
@@ -610,6 +619,21 @@ int swb_set_positions(swb_handle h, const double* x_host, const double* y_host, 
   HIP_TRY(hipMemcpy(h->d_y, y_host, NS * 8, hipMemcpyHostToDevice));
   return SWB_OK;
 }
+
+int swb_variant(swb_handle h, swb_variant_info* out) {
+  if (!h || !out) return fail(SWB_ERR_INVALID, "null argument");
+  const variant* v = pick_variant(h->p.Wc, h->p.Wo, h->vslots);
+  if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d / image width %d not supported", h->p.Wc, h->p.Hc, h->p.Wo);
+  out->nw = v->nw; out->ncol = v->ncol; out->vs = v->vs;
+  out->lds_bytes_per_wave = (int32_t)lds_per_wave(h, v, nullptr);
+  out->waves_per_simd = v->ncol == 1 ? SWB_WAVES_PER_SIMD : (v->ncol == 2 ? 2 : 1);
+  return SWB_OK;
+}
+
+#ifndef SWB_BUILD_ID
+#define SWB_BUILD_ID "unknown"
+#endif
+const char* swb_build_id(void) { return SWB_BUILD_ID; }
 
 int swb_timing_enable(swb_handle h, int32_t enable) {
   if (!h) return fail(SWB_ERR_INVALID, "null handle");

@@ -166,6 +166,13 @@ class DeviceSampler(object):
   # ---------------------------------------------------------------- lowering
   def _group_label(self, sub, dist, marg):
     """Task label of a group's sprites; must not depend on the sampled values."""
+    rng_state = np.random.get_state()      # the probes must not advance the caller's global numpy stream
+    try:
+      return self._group_label_probed(sub, dist, marg)
+    finally:
+      np.random.set_state(rng_state)
+
+  def _group_label_probed(self, sub, dist, marg):
     probes = [dist.sample() for _ in range(256)]
     for key, leaf in marg.items():  # range ends of every continuous factor
       if type(leaf).__name__ == 'Continuous' and leaf.maxval > leaf.minval:

@@ -168,6 +168,15 @@ class Engine(object):
         'success': self.success.cpu().numpy(), 'error': self.error.cpu().numpy(),
     }
 
+  def variant(self):
+    """dict(nw, ncol, vs, lds_bytes_per_wave, waves_per_simd, kernel, build_id): the step kernel this engine launches."""
+    info = _abi.SwbVariantInfo()
+    _lib.check(self.lib.swb_variant(self._h, C.byref(info)))
+    d = {k: getattr(info, k) for k, _ in _abi.SwbVariantInfo._fields_}
+    d['kernel'] = 'swb_step_kernel<%d,%d,%d>' % (info.nw, info.ncol, info.vs)
+    d['build_id'] = self.lib.swb_build_id().decode()
+    return d
+
   def timing(self, enable):
     _lib.check(self.lib.swb_timing_enable(self._h, int(enable)))
 

@@ -13,9 +13,23 @@ the dict a config's `get_config()` returns, plus `num_envs`.  `reset()` /
   tensor), a `Success` renderer's key -> bool[N].
 
 Per-environment auto-reset is the reference's: the step after a LAST step
-ignores its action and returns FIRST (:90-91).  New episodes come from a pool of
-`init_sprites()` draws made on the host (`episodes_per_env` per environment,
-cycled; call `refill_pool()` to draw fresh ones).
+ignores its action and returns FIRST (:90-91).  Where new episodes come from:
+
+  * `device_reset='auto'` (default): when `init_sprites` was built with
+    sprite_generators.* from Product / SetMinus / Continuous / Discrete
+    distributions (every shipped config), episodes are drawn ON THE DEVICE
+    (device_sampler, Philox streams keyed by `seed`) and the idle pool entries
+    are redrawn every `refresh_every` steps, so an environment never meets an
+    episode twice -- the reference's "fresh init_sprites() at every reset";
+  * otherwise (opaque `init_sprites` callables) the pool holds
+    `episodes_per_env` host draws per environment and each environment CYCLES
+    through them: a long run replays these episodes until `refill_pool()` is
+    called (which restarts every environment).  Use a declarative generator, or
+    raise `episodes_per_env`, for training runs.
+
+The tensors of a returned time step (observation, reward, ...) are the engine's
+output buffers: the next `step()` overwrites them in place; clone what must
+outlive a step (e.g. `obs` vs `next_obs`).
 
 `Environment` is the N = 1 form returning `dm_env.TimeStep`s of numpy values, a
 drop-in for the reference class in `example_run_loop.py:62-80`.
@@ -45,7 +59,7 @@ class BatchedEnvironment(object):
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, num_envs=1, episodes_per_env=8,
                max_sprites=None, device=0, check_errors=32, action_dtype=np.float64,
-               global_env_offset=0, device_reset=False, refresh_every=0):
+               global_env_offset=0, device_reset='auto', refresh_every='auto', seed=None):
     self._task = task
     self._action_space = action_space
     self._renderers = renderers
@@ -65,6 +79,10 @@ class BatchedEnvironment(object):
     self._steps_since_check = 0
     # With device-side reset sampling: redraw the idle pool entries every `refresh_every` steps (0: never;
     # refresh_pool() can be called by hand).  episodes_per_env * shortest episode length is a safe period.
+    # 'auto': 2 * (episodes_per_env - 1) steps -- an episode lasts at least two steps (FIRST + one more), so no
+    # environment can run out of unseen entries between two refreshes.
+    if refresh_every == 'auto':
+      refresh_every = 2 * (self._episodes_per_env - 1)
     self._refresh_every = int(refresh_every)
     self._steps_since_refresh = 0
     self._image_key, self._pil = lowering.find_pil_renderer(renderers)
@@ -81,7 +99,10 @@ class BatchedEnvironment(object):
     self._sampler = init_sprites if isinstance(init_sprites, device_sampler.DeviceSampler) else None
     if self._sampler is None and device_reset:
       try:
-        sampler = device_sampler.from_generator(init_sprites)
+        # `seed` keys the Philox episode streams; None draws it from numpy's global stream, so np.random.seed()
+        # makes runs reproducible and different seeds give different episodes
+        sampler = device_sampler.from_generator(
+            init_sprites, seed=int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed))
         sampler.lower(task, renderers)
         self._sampler = sampler
       except lowering.LoweringError:
@@ -201,6 +222,7 @@ class BatchedEnvironment(object):
     self._steps_since_check = 0
     err = int(self._engine.error.max().item())
     if err:
+      self._engine.error.zero_()          # the flags are sticky on the device (include/swb.h): consumed here
       if err & _abi.ENV_ERR_DB_ZERO:
         raise ZeroDivisionError('float division by zero (Davies-Bouldin score is 0)')
       if err & _abi.ENV_ERR_DB_LABELS:
@@ -320,6 +342,14 @@ class Environment(object):
 
   def observation_spec(self):
     return self._batched.observation_spec()
+
+  def reward_spec(self):
+    """dm_env.Environment's default (the reference does not override it): a float scalar."""
+    return dm_env.specs.Array(shape=(), dtype=float, name='reward')
+
+  def discount_spec(self):
+    """dm_env.Environment's default: a float scalar in [0, 1]."""
+    return dm_env.specs.BoundedArray(shape=(), dtype=float, minimum=0., maximum=1., name='discount')
 
   def _convert(self, ts):
     step_type = dm_env.StepType(int(ts.step_type[0].item()))

@@ -68,6 +68,25 @@ _AGG = {'nansum': _abi.AGG_SUM, 'nanmax': _abi.AGG_MAX, 'nanmin': _abi.AGG_MIN,
 _TERM = {'all': _abi.TERM_ALL, 'any': _abi.TERM_ANY}
 
 
+def check_static_labels(task):
+  """Filters and cluster distributions are evaluated once per episode (pool label), which is only the
+  reference's per-step `contains(sprite.factors)` (tasks.py:134-137, 196-204) if they never look at a
+  factor that changes inside an episode: raises when one keys on x or y."""
+  for sub in subtasks_of(task):
+    dists = []
+    if _cls(sub) == 'FindGoalPosition' and sub._filter_distrib is not None:
+      dists.append(sub._filter_distrib)
+    elif _cls(sub) == 'Clustering':
+      dists.extend(sub._cluster_distribs)
+    for d in dists:
+      keys = getattr(d, 'keys', None)
+      keys = set(keys() if callable(keys) else (keys or ()))
+      moving = sorted(keys & {'x', 'y'})
+      if moving:
+        raise LoweringError('task filter / cluster distribution keys on %s, which change during an episode: '
+                            'membership cannot be fixed at reset (step this task with the CPU reference)' % moving)
+
+
 def subtasks_of(task):
   """[sub-tasks] of a MetaAggregated task, or [task]."""
   return list(task._subtasks) if _cls(task) == 'MetaAggregated' else [task]
@@ -95,6 +114,7 @@ def lower_config(task, action_space, renderers, keep_in_frame=True, max_episode_
   np.float32 (what its `action_spec()` declares); numpy's promotion rules make the two
   differ in the last bits of motions, click offsets and some rewards, so the engine follows
   whichever the caller uses.  Ignored for Embodied (integer actions)."""
+  check_static_labels(task)
   cfg = _abi.SwbConfig()
   cfg.n_envs = int(num_envs)
   cfg.max_sprites = int(max_sprites)
@@ -232,6 +252,7 @@ def position_dtype(episodes):
 
 def lower_episodes(episodes, task, renderers, max_sprites=None):
   """List of sprite lists (one per reset, back-to-front order) -> Pool."""
+  check_static_labels(task)
   subs = subtasks_of(task)
   _, pil = find_pil_renderer(renderers)
   to_rgb = pil._color_to_rgb if pil is not None else (lambda c: (0, 0, 0))

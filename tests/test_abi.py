@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_header(tmp_path):
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(swb_task), sizeof(swb_config), sizeof(swb_pool),
          sizeof(swb_outputs), sizeof(swb_state), sizeof(swb_factor), sizeof(swb_sprite_group), sizeof(swb_sampler));
-  printf("%zu %zu\\n", sizeof(swb_holdout), sizeof(swb_alternative));
+  printf("%zu %zu %zu\\n", sizeof(swb_holdout), sizeof(swb_alternative), sizeof(swb_variant_info));
   printf("%zu %zu %zu %zu\\n", offsetof(swb_config, action_scale), offsetof(swb_config, n_tasks),
          offsetof(swb_config, meta_terminate_bonus), offsetof(swb_config, tasks));
   return 0;
@@ -51,7 +51,7 @@ int main(void) {
   out = subprocess.check_output([str(exe)]).decode().split()
   got = [ctypes.sizeof(c) for c in (_abi.SwbTask, _abi.SwbConfig, _abi.SwbPool, _abi.SwbOutputs, _abi.SwbState,
                                      _abi.SwbFactor, _abi.SwbSpriteGroup, _abi.SwbSampler, _abi.SwbHoldout,
-                                     _abi.SwbAlternative)]
+                                     _abi.SwbAlternative, _abi.SwbVariantInfo)]
   got += [getattr(_abi.SwbConfig, f).offset for f in ('action_scale', 'n_tasks', 'meta_terminate_bonus', 'tasks')]
   assert [int(v) for v in out] == got
 

@@ -299,7 +299,8 @@ def _make_env(case, num_envs=48, episodes_per_env=3):
   sampler, task, rend = CASES[case]()
   env = environment.BatchedEnvironment(task=task, action_space=action_spaces.SelectMove(scale=0.25),
                                        renderers=rend, init_sprites=sampler, max_episode_length=6,
-                                       num_envs=num_envs, episodes_per_env=episodes_per_env)
+                                       num_envs=num_envs, episodes_per_env=episodes_per_env,
+                                       refresh_every=0)      # the pool is compared / cloned below: keep it still
   return env, sampler, task, rend
 
 

@@ -41,14 +41,33 @@ def _clone_cfg(cfg, n):
   return c
 
 
-@pytest.mark.parametrize('name', ['cluster_s5', 'goal_s5'])
-def test_sample_of_full_batch_matches_oracle(name):
+@pytest.mark.parametrize('name,n_envs,epe,steps', [('cluster_s5', N, 3, 24), ('goal_s5', N, 3, 24),
+                                                   ('embodied_s12', N, 2, 12),       # BASELINE configs[4]
+                                                   ('cluster_s5', 65536, 2, 8)])     # configs[3]'s batch in ONE launch
+def test_sample_of_full_batch_matches_oracle(name, n_envs, epe, steps):
+  import torch
   from oracle import oracle
   from spriteworld_amd import engine
-  epe, steps = 3, 24
-  cfg, pool, sample = workloads.build(name, N, episodes_per_env=epe, seed=5, anti_aliasing=5)
+  cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=epe, seed=5, anti_aliasing=5)
   eng = engine.Engine(cfg, pool)
-  pick = np.sort(np.random.default_rng(1).choice(N, 96, replace=False))
+  pick = np.sort(np.random.default_rng(1).choice(n_envs, 96, replace=False))
+  if n_envs > N:                      # a big batch: only the sampled environments leave the device
+    ora = oracle.Engine(_clone_cfg(cfg, len(pick)), _sub_pool(pool, pick, epe))
+    rng = np.random.default_rng(9)
+    idx = torch.as_tensor(pick, device=eng.device)
+    for t in range(steps):
+      a = sample(rng)
+      eng.step(a)
+      want = ora.step(a[pick])
+      assert int(eng.error.max().item()) == 0
+      assert np.array_equal(eng.obs[idx].cpu().numpy(), want['obs']), t
+      assert np.array_equal(eng.step_type[idx].cpu().numpy(), want['step_type']), t
+      assert np.array_equal(eng.reward[idx].cpu().numpy().view(np.uint64), want['reward'].view(np.uint64)), t
+      assert np.array_equal(eng.success[idx].cpu().numpy(), want['success']), t
+    st_g, st_o = eng.state(), ora.state()
+    assert np.array_equal(st_g['x'][pick], st_o['x']) and np.array_equal(st_g['y'][pick], st_o['y'])
+    eng.close()
+    return
   ora = oracle.Engine(_clone_cfg(cfg, len(pick)), _sub_pool(pool, pick, epe))
   rng = np.random.default_rng(9)
   for t in range(steps):

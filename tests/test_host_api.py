@@ -154,7 +154,7 @@ def test_sprite_factors_observation_and_action_noise():
   config = _cobra_like_config()
   config['renderers'] = {'factors': renderers.SpriteFactors(), 'xy': renderers.SpriteFactors(factors=('y', 'x', 'shape'))}
   config['action_space'] = action_spaces.SelectMove(scale=0.25, noise_scale=0.05)
-  env = environment.BatchedEnvironment(num_envs=32, episodes_per_env=2, **config)
+  env = environment.BatchedEnvironment(num_envs=32, episodes_per_env=2, device_reset=False, **config)   # host pool: compared below
   env.seed_noise(0)
   ts = env.reset()
   f = ts.observation['factors'].cpu().numpy()
@@ -183,9 +183,9 @@ def test_environment_groups_equal_the_groups_stepped_alone():
   from spriteworld_amd import environment
   config = _cobra_like_config()
   np.random.seed(11)
-  groups = environment.EnvironmentGroups(num_groups=2, num_envs=64, **config)
+  groups = environment.EnvironmentGroups(num_groups=2, num_envs=64, device_reset=False, **config)
   np.random.seed(11)
-  alone = [environment.BatchedEnvironment(num_envs=32, **config) for _ in range(2)]
+  alone = [environment.BatchedEnvironment(num_envs=32, device_reset=False, **config) for _ in range(2)]
   gen = torch.Generator().manual_seed(4)
   for g in range(2):
     a, b = groups.reset(g), alone[g].reset()
