@@ -77,7 +77,8 @@ struct swb_engine {
   double *d_x = nullptr, *d_y = nullptr;
   int32_t *d_nspr = nullptr, *d_entry = nullptr, *d_step_count = nullptr, *d_episode = nullptr;
   uint8_t* d_reset_next = nullptr;
-  uint32_t* d_ovf = nullptr;
+  uint32_t *d_ovf = nullptr, *d_ovf_bitmap = nullptr;
+  int ovf_slots = 0;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -121,6 +122,25 @@ size_t lds_per_wave(const swb_engine* h, const variant* v, int* cpath_in_masks) 
   if (cpath_in_masks) *cpath_in_masks = in_masks;
   return (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
           (size_t)p.max_spans * SWB_WAVE * 4 + (in_masks ? 0 : cpath_bytes) + 15) & ~(size_t)15;
+}
+
+// Overflow slots for the span lists: one per wave that can be resident at once (occupancy of this
+// variant with its LDS footprint x CUs, capped by the batch), never one per environment.
+int ensure_overflow_slots(swb_engine* h, const variant* v, size_t lds_bytes) {
+  if (h->d_ovf) return 0;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(v->fn), SWB_WAVE * SWB_WAVES_PER_BLOCK,
+                                                   lds_bytes) != hipSuccess || per_cu < 1)
+    per_cu = 32;
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+  long long slots = (long long)per_cu * SWB_WAVES_PER_BLOCK * cus;
+  slots = std::min<long long>(slots + slots / 4, (long long)h->p.N);      // 25 % margin over the occupancy query
+  slots = (slots + 31) / 32 * 32;
+  h->ovf_slots = (int)slots;
+  if (upload(&h->d_ovf, (const uint32_t*)nullptr, (size_t)slots * 64 * h->p.ovf_cap)) return SWB_ERR_HIP;
+  if (upload(&h->d_ovf_bitmap, (const uint32_t*)nullptr, (size_t)slots / 32)) return SWB_ERR_HIP;
+  h->p.ovf = h->d_ovf; h->p.ovf_bitmap = h->d_ovf_bitmap; h->p.ovf_slots = h->ovf_slots;
+  return 0;
 }
 
 int flush_timing(swb_engine* h) {
@@ -169,6 +189,10 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(v->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (!h->d_ovf) {
+    if (int rc = ensure_overflow_slots(h, v, lds)) return rc;
+    p.ovf = h->p.ovf; p.ovf_bitmap = h->p.ovf_bitmap; p.ovf_slots = h->p.ovf_slots;
+  }
   const int blocks = (c.n_envs + SWB_WAVES_PER_BLOCK - 1) / SWB_WAVES_PER_BLOCK;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) {
@@ -241,14 +265,14 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   rc |= upload(&h->d_episode, (const int32_t*)nullptr, p.N);
   rc |= upload(&h->d_reset_next, (const uint8_t*)nullptr, p.N);
   if (rc) { swb_destroy(h); return SWB_ERR_HIP; }
-  // visible-span lists: M per canvas row in LDS, the (never expected) rest in HBM; a row of Wc
-  // pixels has at most Wc/2 + 1 runs, so M + ovf_cap >= that bound makes overflow impossible.
   p.max_spans = SWB_MIN_SPANS;
   if (const char* ms = getenv("SWB_MAX_SPANS")) p.max_spans = atoi(ms) < SWB_MIN_SPANS ? SWB_MIN_SPANS : atoi(ms);
-  p.ovf_cap = p.Wc / 2 + 1;
-  rc |= upload(&h->d_ovf, (const uint32_t*)nullptr, (size_t)p.N * 64 * p.ovf_cap);
-  if (rc) { swb_destroy(h); return SWB_ERR_HIP; }
-  p.ovf = h->d_ovf;
+  p.span_cap = p.max_spans;
+  if (const char* sc = getenv("SWB_LDS_SPAN_CAP")) p.span_cap = std::max(0, std::min(atoi(sc), p.max_spans));   // tests
+  // visible-span lists: 3 per canvas row in registers, M in LDS, up to ovf_cap more in an HBM slot that a wave
+  // takes only when a row of its batch needs it (allocated at the first launch, see ensure_overflow_slots)
+  p.ovf_cap = std::min(p.Wc / 2 + 1, 32);
+  p.ovf = nullptr;
   p.x = h->d_x; p.y = h->d_y; p.nspr = h->d_nspr; p.entry = h->d_entry; p.step_count = h->d_step_count;
   p.episode = h->d_episode; p.reset_next = h->d_reset_next;
   *out = h;
@@ -262,7 +286,7 @@ int swb_destroy(swb_handle h) {
   void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
-                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_p_angle, h->d_p_color, h->d_sampler};
+                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;

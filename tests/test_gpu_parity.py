@@ -109,6 +109,15 @@ def test_tiny_sprites_aa1():
   _run('tiny_s6', 256, 6, 1)
 
 
+@pytest.mark.parametrize('name,n_envs,aa', [('embodied_s12', 48, 5), ('ragged_s16', 96, 5), ('wide_s4', 64, 5), ('cluster_s5', 128, 1)])
+def test_span_lists_spill_to_the_hbm_overflow_slots(monkeypatch, name, n_envs, aa):
+  """Rows with more than three visible spans normally continue in LDS; with the LDS lists switched off
+  (SWB_LDS_SPAN_CAP=0, read by swb_create) every such row takes the HBM overflow path: a slot from the
+  bitmap on first use, given back at kernel end (so consecutive steps reuse the few slots)."""
+  monkeypatch.setenv('SWB_LDS_SPAN_CAP', '0')
+  _run(name, n_envs, 8, aa)
+
+
 @pytest.mark.parametrize('name,aa', [('goal_s5_f32a', 5), ('cluster_s5_f32a', 5), ('f64_drag_f32a', 3),
                                      ('f64_cluster_f32a', 3), ('sorting_s4_f32a', 5)])
 def test_float32_actions(name, aa):
