@@ -56,6 +56,8 @@ struct swb_engine {
   swb_params p;        // device pointers + config, passed by value to the kernel
   bool have_shapes = false, have_h = false, have_v = false, have_pool = false;
   int nw = 0, ncol = 0, vslots = SWB_VSLOTS;
+  std::vector<int> shape_nverts;     // vertices per uploaded shape
+  int ovf_lds_bytes = 0;             // LDS footprint the overflow slots were sized with
   size_t lds_block = 0;
   // owned device buffers
   double* d_shape_verts = nullptr;
@@ -113,15 +115,16 @@ const variant* pick_variant(int Wc, int Wo, int vslots = SWB_VSLOTS) {
   return nullptr;
 }
 
-// LDS bytes of one wave (= one environment) of variant v: wave_lds + edge records + span lists
-// (+ the centred paths, 16 B per vertex, when the idle mask arrays are too small to hold them).
+// LDS bytes of one wave (= one environment) of variant v: wave_lds + edge records + span lists.  The
+// centred paths (16 B per vertex) borrow the idle mask arrays, or the edge records' storage.
 size_t lds_per_wave(const swb_engine* h, const variant* v, int* cpath_in_masks) {
   const swb_params& p = h->p;
   const size_t cpath_bytes = (size_t)p.max_edges * 16;
   const int in_masks = (2 * (size_t)SWB_NWA(v->nw) * SWB_WAVE * 4 >= cpath_bytes) ? 1 : 0;
   if (cpath_in_masks) *cpath_in_masks = in_masks;
+  (void)cpath_bytes;      // when not in the masks, the centred paths live in the edge records' storage (same 16 B per index)
   return (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
-          (size_t)p.max_spans * SWB_WAVE * 4 + (in_masks ? 0 : cpath_bytes) + 15) & ~(size_t)15;
+          (size_t)p.max_spans * SWB_WAVE * 4 + 15) & ~(size_t)15;
 }
 
 // Overflow slots for the span lists: one per wave that can be resident at once (occupancy of this
@@ -189,8 +192,14 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(v->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (!h->d_ovf) {
+  if (!h->d_ovf || (int)lds < h->ovf_lds_bytes) {      // first launch, or a new pool shrank the LDS footprint (more waves resident)
+    if (h->d_ovf) {
+      HIP_TRY(hipDeviceSynchronize());
+      (void)hipFree(h->d_ovf); (void)hipFree(h->d_ovf_bitmap);
+      h->d_ovf = nullptr; h->d_ovf_bitmap = nullptr;
+    }
     if (int rc = ensure_overflow_slots(h, v, lds)) return rc;
+    h->ovf_lds_bytes = (int)lds;
     p.ovf = h->p.ovf; p.ovf_bitmap = h->p.ovf_bitmap; p.ovf_slots = h->p.ovf_slots;
   }
   const int blocks = (c.n_envs + SWB_WAVES_PER_BLOCK - 1) / SWB_WAVES_PER_BLOCK;
@@ -319,7 +328,9 @@ int swb_upload_shapes(swb_handle h, const double* verts, const int32_t* offsets,
   h->p.shape_verts = h->d_shape_verts;
   h->p.shape_off = h->d_shape_off;
   h->p.max_verts = maxv;
-  h->p.max_edges = maxv * h->p.S;
+  h->p.max_edges = maxv * h->p.S;                 // until a pool is installed (then: the pool's largest episode)
+  h->shape_nverts.resize(n_shapes);
+  for (int i = 0; i < n_shapes; ++i) h->shape_nverts[i] = offsets[i + 1] - offsets[i];
   h->have_shapes = true;
   return SWB_OK;
 }
@@ -439,6 +450,20 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
   p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
   h->pool_entries = P;
   h->pool_sampled = false;
+  // polygon vertices of the largest episode: sizes the per-wave edge records and centred paths in LDS
+  if (h->have_shapes) {
+    int most = 1;
+    for (int e = 0; e < P; ++e) {
+      int tot = 0;
+      for (int s2 = 0; s2 < pool->n_sprites[e]; ++s2) {
+        const int sh = pool->shape[(size_t)e * S + s2];
+        if (sh >= (int)h->shape_nverts.size()) return fail(SWB_ERR_INVALID, "pool entry %d uses shape %d, %zu shapes uploaded", e, sh, h->shape_nverts.size());
+        tot += h->shape_nverts[sh];
+      }
+      most = std::max(most, tot);
+    }
+    h->p.max_edges = (most + 3) & ~3;
+  }
   HIP_TRY(hipMemset(h->d_reset_next, 1, N));      // environment.py:70
   HIP_TRY(hipMemset(h->d_episode, 0, sizeof(int32_t) * N));
   HIP_TRY(hipMemset(h->d_step_count, 0, sizeof(int32_t) * N));
@@ -500,6 +525,25 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
     }
   }
   if (max_total > S) return fail(SWB_ERR_INVALID, "sampler can emit %d sprites (max_sprites %d)", max_total, S);
+  if (h->have_shapes) {       // the most polygon vertices an episode of this sampler can have (LDS sizing)
+    auto group_verts = [&](const swb_sprite_group& grp) {
+      int mv = 0;
+      for (int i = 0; i < grp.n_shapes; ++i)
+        if (grp.shapes[i] < (int)h->shape_nverts.size()) mv = std::max(mv, h->shape_nverts[grp.shapes[i]]);
+      return mv * grp.count_max;
+    };
+    int most = 0;
+    if (spec->n_alternatives > 0) {
+      for (int i = 0; i < spec->n_alternatives; ++i) {
+        int tot = 0;
+        for (int g = 0; g < spec->alternatives[i].n; ++g) tot += group_verts(spec->groups[spec->alternatives[i].group[g]]);
+        most = std::max(most, tot);
+      }
+    } else {
+      for (int g = 0; g < spec->n_groups; ++g) most += group_verts(spec->groups[g]);
+    }
+    h->p.max_edges = (std::max(most, 1) + 3) & ~3;
+  }
   for (int i = 0; i < N; ++i)
     if (pool_len_host[i] < 1 || pool_base_host[i] < 0 || pool_base_host[i] + pool_len_host[i] > P)
       return fail(SWB_ERR_INVALID, "env %d: pool range [%d, +%d) outside the pool of %d", i, pool_base_host[i], pool_len_host[i], P);
@@ -650,7 +694,7 @@ int swb_variant(swb_handle h, swb_variant_info* out) {
   if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d / image width %d not supported", h->p.Wc, h->p.Hc, h->p.Wo);
   out->nw = v->nw; out->ncol = v->ncol; out->vs = v->vs;
   out->lds_bytes_per_wave = (int32_t)lds_per_wave(h, v, nullptr);
-  out->waves_per_simd = v->ncol == 1 ? SWB_WAVES_PER_SIMD : (v->ncol == 2 ? 2 : 1);
+  out->waves_per_simd = v->ncol == 1 ? SWB_WAVES_PER_SIMD : (v->ncol == 2 ? SWB_WAVES_PER_SIMD_2COL : 1);
   return SWB_OK;
 }
 
