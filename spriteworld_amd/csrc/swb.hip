@@ -188,7 +188,8 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   p.cpath_in_masks = cpath_in_masks;
   p.lds_per_wave = (int32_t)per_wave;
   p.outrow_bytes = (int32_t)v->outrow_bytes;
-  const size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
+  size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
+  if (const char* x = getenv("SWB_EXTRA_LDS")) lds += (size_t)atoi(x);      // occupancy experiments only (tools/r02_occ.sh)
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(v->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
