@@ -5,11 +5,15 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-SOURCES = ('swb.hip', 'swb_kernels.hip.inc', 'swb_pow.hip.inc', 'swb_pow_tables.inc', 'swb_sampler.hip.inc')
-# -amdgpu-sched-strategy=iterative-ilp: the ILP-first list scheduler measured 3 % faster than the
-# default on the step kernel (tools/exp_libs.sh), same results bit for bit.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math',
-         '-mllvm', '-amdgpu-sched-strategy=iterative-ilp', '-shared', '-fPIC']
+SOURCES = ('swb.hip', 'swb_wide.hip', 'swb_kernels.hip.inc', 'swb_pow.hip.inc', 'swb_pow_tables.inc', 'swb_sampler.hip.inc')
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-fPIC']
+# Two translation units, two instruction schedulers (same results bit for bit; measured on MI355X, round 2):
+#   swb.hip       host code + the kernels of images up to 64 columns: LLVM's default strategy -- as fast as the
+#                 ILP-first one at 4 waves per SIMD (0.243 vs 0.247 ms) with 11 instead of 69 spilled VGPRs;
+#   swb_wide.hip  the kernels of wider images (2-3 waves per SIMD): -amdgpu-sched-strategy=iterative-ilp,
+#                 5 % faster there (2.31 vs 2.43 ms on 12 sprites, 128x128).
+UNITS = (('swb.hip', []), ('swb_wide.hip', ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']))
+FLAGS = COMMON + ['units=' + ';'.join('%s:%s' % (u, ' '.join(f)) for u, f in UNITS)]      # hashed with the sources
 
 
 def source_hash():
@@ -34,7 +38,18 @@ def build(force=False, verbose=False):
   hipcc = os.environ.get('HIPCC', 'hipcc')
   if not any(os.access(os.path.join(d, hipcc), os.X_OK) for d in os.environ['PATH'].split(':')):
     hipcc = '/opt/rocm/bin/hipcc'
-  cmd = [hipcc] + FLAGS + ['-DSWB_BUILD_ID="%s"' % want[:16], '-o', out, os.path.join(CSRC, 'swb.hip')]
+  objs, procs = [], []
+  for unit, extra in UNITS:                       # the two units compile in parallel
+    obj = os.path.join(CSRC, unit.replace('.hip', '.o'))
+    cmd = [hipcc] + COMMON + extra + ['-DSWB_BUILD_ID="%s"' % want[:16], '-c', '-o', obj, os.path.join(CSRC, unit)]
+    if verbose:
+      print(' '.join(cmd))
+    procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    objs.append(obj)
+  for cmd, proc in procs:
+    if proc.wait() != 0:
+      raise subprocess.CalledProcessError(proc.returncode, cmd)
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs
   if verbose:
     print(' '.join(cmd))
   subprocess.check_call(cmd, cwd=CSRC)

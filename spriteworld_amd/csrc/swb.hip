@@ -18,6 +18,14 @@
 #include "swb_pow.hip.inc"
 #include "swb_sampler.hip.inc"
 
+// the kernels of images wider than 64 columns are instantiated in swb_wide.hip (other scheduler flags)
+extern template __global__ void swb_step_kernel<4, 2, 8>(const swb_params);
+extern template __global__ void swb_step_kernel<10, 2, 8>(const swb_params);
+extern template __global__ void swb_step_kernel<20, 2, 6>(const swb_params);
+extern template __global__ void swb_step_kernel<20, 2, 8>(const swb_params);
+extern template __global__ void swb_step_kernel<20, 4, 8>(const swb_params);
+
+
 namespace {
 
 thread_local std::string g_err;
