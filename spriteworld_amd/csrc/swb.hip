@@ -145,7 +145,7 @@ int ensure_overflow_slots(swb_engine* h, const variant* v, size_t lds_bytes) {
     per_cu = 32;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
   long long slots = (long long)per_cu * SWB_WAVES_PER_BLOCK * cus;
-  slots = std::min<long long>(slots + slots / 4, (long long)h->p.N);      // 25 % margin over the occupancy query
+  slots = std::min<long long>(2 * slots, (long long)h->p.N);              // the bitmap stays at most half full: few retries
   slots = (slots + 31) / 32 * 32;
   h->ovf_slots = (int)slots;
   if (upload(&h->d_ovf, (const uint32_t*)nullptr, (size_t)slots * 64 * h->p.ovf_cap)) return SWB_ERR_HIP;
