@@ -60,8 +60,7 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     pool = synthetic.make_pool(rng, P, 5, hues, labels)
     cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 5, True)
   elif name == 'cluster6_s12':
-    # six clusters of two: more clusters than the wave-parallel Davies-Bouldin handles (scalar path),
-    # float32 positions; one sprite in no cluster
+    # six clusters of two (a 6 x 6 Davies-Bouldin ratio matrix), float32 positions; one sprite in no cluster
     task = tasks.Clustering([None] * 6, termination_threshold=1.2, terminate_bonus=1., reward_range=6.)
     aspace = action_spaces.SelectMove(scale=0.25)
     rend = _renderers(64, aa)
