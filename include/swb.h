@@ -289,6 +289,43 @@ int swb_factors(swb_handle h, double* factors_dev, void* stream);
 int swb_get_state(swb_handle h, const swb_state* host_state, void* stream);
 int swb_set_positions(swb_handle h, const double* x_host, const double* y_host, void* stream);
 
+/* Sprite attribute setters on a LIVE sprite (sprite.py:152-175; pinned by the reference's
+ * tests/sprite_test.py:138-174), for sprite `sprite` of environment `env` in its current episode:
+ *   SWB_ATTR_SHAPE  value = index into the uploaded shape table: _shape = s; _reset_centered_path()
+ *                   (a fresh path from the new shape and the CURRENT scale and angle, :96-101)
+ *   SWB_ATTR_ANGLE  value = degrees: the current centred path is rotated by (value - angle)   (:161-165)
+ *   SWB_ATTR_SCALE  value = scale:   the current centred path is scaled by (value - scale) -- the
+ *                   DIFFERENCE, as the reference does (:171-175), not the ratio
+ * The transforms are incremental, exactly like the reference's (matplotlib Affine2D + transform_path,
+ * restated on the host): after a setter the sprite's centred path is no longer a function of its
+ * factors, so the library keeps the path itself (device memory, allocated at the first call: N x S x
+ * SWB_MAX_SHAPE_VERTS x 16 B) and the engine switches to the kernel build that reads it.  hit-tests
+ * (contains_point), rendering and the SpriteFactors observation all see the new attribute; the
+ * overrides end with the episode (the next reset draws fresh sprites, environment.py:74-78).
+ *   delta  NULL: the difference (value - old) is taken in float64 from the stored factor.  Non-NULL:
+ *          the difference the caller computed (e.g. in float32, when the sprite's factor is an
+ *          np.float32 and numpy's promotion rules keep `a - self._angle` in float32).
+ *   label  NULL: the sprite keeps its task labels.  Non-NULL: i8[n_tasks] new labels (the caller
+ *          re-evaluated `filter.contains(sprite.factors)`, tasks.py:134-137,196-205, for filters that
+ *          key on the changed attribute).
+ * Blocking (synchronises `stream`); SWB_ERR_STATE when the environment has no live episode (never
+ * reset, or its episode just ended).  Not part of the step path: call rates of a few per second. */
+enum swb_sprite_attr { SWB_ATTR_SHAPE = 0, SWB_ATTR_ANGLE = 1, SWB_ATTR_SCALE = 2 };
+int swb_set_sprite_attr(swb_handle h, int32_t env, int32_t sprite, int32_t attr, double value, const double* delta,
+                        const int8_t* label, void* stream);
+
+/* The sprite as the engine currently sees it: shape index, angle, scale, and its centred path
+ * (Sprite._centered_path.vertices, sprite.py:96-101) -- path_xy f64[SWB_MAX_SHAPE_VERTS][2], n_verts
+ * entries written.  Any output pointer may be NULL.  Blocking. */
+int swb_get_sprite(swb_handle h, int32_t env, int32_t sprite, int32_t* shape, double* angle, double* scale, int32_t* n_verts,
+                   double* path_xy, void* stream);
+
+/* The host arithmetic of the setters alone (no device access; for tests against matplotlib):
+ *   SWB_ATTR_SHAPE  out = _reset_centered_path of the unit-scale vertices `in_xy` with scale = a, angle = b (degrees)
+ *   SWB_ATTR_ANGLE  out = Affine2D().rotate_deg(a - b).transform_path(in)
+ *   SWB_ATTR_SCALE  out = Affine2D().scale(a - b).transform_path(in) */
+int swb_sprite_path_op(int32_t attr, double a, double b, int32_t n, const double* in_xy, double* out_xy);
+
 /* Which build of the fused step kernel swb_step launches for this handle -- the template parameters
  * of swb_step_kernel<NW, NCOL, VS> (32-pixel canvas words per row, output columns per lane, output
  * rows in flight in the vertical pass) and its LDS footprint -- so that measurement code labels a

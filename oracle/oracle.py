@@ -46,6 +46,8 @@ def lib():
     _lib.swo_get_state.argtypes = [C.c_void_p, C.c_void_p]
     _lib.swo_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _lib.swo_contains_point.argtypes = [C.c_int] + [C.c_double] * 5
+    _lib.swo_set_sprite_attr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    _lib.swo_get_sprite.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     verts, offs = _shapes.packed_table()
     rc = _lib.swo_set_shapes(verts.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
                              C.c_int32(len(offs) - 1))
@@ -191,3 +193,22 @@ class Engine(object):
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
     lib().swo_set_positions(self._h, _p(x), _p(y))
+
+  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
+    """sprite.py:152-175 setters on a live sprite (attr: _abi.ATTR_SHAPE / ATTR_ANGLE / ATTR_SCALE)."""
+    d = None if delta is None else C.byref(C.c_double(float(delta)))
+    lab = None if label is None else np.ascontiguousarray(label, dtype=np.int8)
+    rc = lib().swo_set_sprite_attr(self._h, int(env), int(sprite), int(attr), float(value), d, _p(lab))
+    if rc != 0:
+      raise ValueError('swo_set_sprite_attr failed (%d)' % rc)
+
+  def get_sprite(self, env, sprite):
+    """dict(shape=index, angle, scale, path=f64[n,2]): the sprite as the oracle currently sees it."""
+    shape, nv = C.c_int32(0), C.c_int32(0)
+    angle, scale = C.c_double(0.0), C.c_double(0.0)
+    path = np.zeros((_abi.SWB_MAX_SHAPE_VERTS, 2), dtype=np.float64)
+    rc = lib().swo_get_sprite(self._h, int(env), int(sprite), C.byref(shape), C.byref(angle), C.byref(scale),
+                              C.byref(nv), _p(path))
+    if rc != 0:
+      raise ValueError('swo_get_sprite failed (%d)' % rc)
+    return {'shape': shape.value, 'angle': angle.value, 'scale': scale.value, 'path': path[:nv.value].copy()}

@@ -400,7 +400,7 @@ int swo_resample(const uint8_t* src, int Wc, int Hc, uint8_t* dst, int W, int H)
  * PIL width Wp = AA*image_h, PIL height Hp = AA*image_w. */
 static void render_env(const swb_config* cfg, int n, const double* x, const double* y,
                        const int32_t* shape, const double* scale, const double* ca,
-                       const double* sa, const uint8_t* rgb, uint8_t* obs) {
+                       const double* sa, const uint8_t* rgb, uint8_t* obs, const double* paths) {
   const int AA = cfg->anti_aliasing;
   const int Wo = cfg->image_h, Ho = cfg->image_w;     /* PIL (width, height) of the output */
   const int Wc = AA * Wo, Hc = AA * Ho;
@@ -411,7 +411,16 @@ static void render_env(const swb_config* cfg, int n, const double* x, const doub
   double cx[SWB_MAX_SHAPE_VERTS], cy[SWB_MAX_SHAPE_VERTS];
   int ixy[2 * SWB_MAX_SHAPE_VERTS];
   for (int s = 0; s < n; ++s) {                         /* back to front :80-83 */
-    const int nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+    int nv;
+    if (paths) {                                        /* centred paths as the attribute setters left them (sprite.py:152-175) */
+      nv = g_off[shape[s] + 1] - g_off[shape[s]];
+      for (int i = 0; i < nv; ++i) {
+        cx[i] = paths[((size_t)s * SWB_MAX_SHAPE_VERTS + i) * 2];
+        cy[i] = paths[((size_t)s * SWB_MAX_SHAPE_VERTS + i) * 2 + 1];
+      }
+    } else {
+      nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+    }
     for (int i = 0; i < nv; ++i) {
       const double vx = 1.0 * cx[i] + 0.0 * cy[i] + x[s]; /* sprite.py:131-133 */
       const double vy = 0.0 * cx[i] + 1.0 * cy[i] + y[s];
@@ -706,11 +715,30 @@ typedef struct {
   double *p_x, *p_y, *p_xv, *p_yv, *p_scale, *p_ca, *p_sa;
   uint8_t* p_rgb;
   int8_t* p_label;
+  double* p_angle;   /* may be NULL */
   /* live */
   double *x, *y;
   int32_t *n, *entry, *step_count, *episode;
   uint8_t* reset_next;
+  /* sprite.py:152-175 attribute setters: per-environment records that replace the pool's static sprite
+   * columns for the rest of the episode (allocated by the first swo_set_sprite_attr) */
+  uint8_t* ov_flag;   /* [N] */
+  int32_t* ov_shape;  /* [N][S] */
+  double *ov_scale, *ov_angle, *ov_cpath;   /* [N][S], [N][S], [N][S][SWB_MAX_SHAPE_VERTS][2] */
+  int8_t* ov_label;   /* [N][T][S] */
 } swo_engine;
+
+/* The centred path of sprite s of environment i: as the setters left it, else fresh from the pool. */
+static int env_path(const swo_engine* e, int i, int s, double* cx, double* cy) {
+  const int S = e->cfg.max_sprites, en = e->entry[i];
+  if (e->ov_flag && e->ov_flag[i]) {
+    const int sh = e->ov_shape[i * S + s], nv = g_off[sh + 1] - g_off[sh];
+    const double* q = e->ov_cpath + ((size_t)i * S + s) * SWB_MAX_SHAPE_VERTS * 2;
+    for (int k = 0; k < nv; ++k) { cx[k] = q[2 * k]; cy[k] = q[2 * k + 1]; }
+    return nv;
+  }
+  return centered_path(e->p_shape[en * S + s], e->p_scale[en * S + s], e->p_ca[en * S + s], e->p_sa[en * S + s], cx, cy);
+}
 
 static void* dup_mem(const void* p, size_t bytes) {
   void* q = malloc(bytes ? bytes : 1);
@@ -736,6 +764,7 @@ swo_engine* swo_create(const swb_config* cfg, const swb_pool* pool) {
   e->p_sa = dup_mem(pool->sin_a, sizeof(double) * P * S);
   e->p_rgb = dup_mem(pool->rgb, (size_t)P * S * 4);
   e->p_label = dup_mem(pool->label, (size_t)P * T * S);
+  e->p_angle = pool->angle ? dup_mem(pool->angle, sizeof(double) * P * S) : NULL;
   e->x = calloc((size_t)N * S, sizeof(double));
   e->y = calloc((size_t)N * S, sizeof(double));
   e->n = calloc(N, sizeof(int32_t));
@@ -756,7 +785,9 @@ void swo_destroy(swo_engine* e) {
   free(e->p_x); free(e->p_y); free(e->p_xv); free(e->p_yv); free(e->p_scale);
   free(e->p_ca); free(e->p_sa); free(e->p_rgb); free(e->p_label);
   free(e->x); free(e->y); free(e->n); free(e->entry); free(e->step_count);
-  free(e->episode); free(e->reset_next); free(e);
+  free(e->episode); free(e->reset_next);
+  free(e->p_angle); free(e->ov_flag); free(e->ov_shape); free(e->ov_scale); free(e->ov_angle); free(e->ov_cpath); free(e->ov_label);
+  free(e);
 }
 
 void swo_reset_all(swo_engine* e) { memset(e->reset_next, 1, e->cfg.n_envs); }
@@ -775,14 +806,17 @@ static void observe(swo_engine* e, int i, uint8_t* obs, uint8_t* succ_out, uint8
   const swb_config* c = &e->cfg;
   const int S = c->max_sprites, en = e->entry[i], n = e->n[i];
   double r = 0; int ok = 0;
-  const int err = eval_task(c, n, e->x + i * S, e->y + i * S, e->p_label + (size_t)en * c->n_tasks * S, &r, &ok);
+  const int ov = e->ov_flag && e->ov_flag[i];
+  const int8_t* label = ov ? e->ov_label + (size_t)i * c->n_tasks * S : e->p_label + (size_t)en * c->n_tasks * S;
+  const int err = eval_task(c, n, e->x + i * S, e->y + i * S, label, &r, &ok);
   if (task_reward) *task_reward = r;
   if (succ_out) *succ_out = (uint8_t)ok;
   if (err_out) *err_out = (uint8_t)err;
   if (obs)
-    render_env(c, n, e->x + i * S, e->y + i * S, e->p_shape + en * S, e->p_scale + en * S,
+    render_env(c, n, e->x + i * S, e->y + i * S, ov ? e->ov_shape + i * S : e->p_shape + en * S, e->p_scale + en * S,
                e->p_ca + en * S, e->p_sa + en * S, e->p_rgb + (size_t)en * S * 4,
-               obs + (size_t)i * c->image_h * c->image_w * 3);
+               obs + (size_t)i * c->image_h * c->image_w * 3,
+               ov ? e->ov_cpath + (size_t)i * S * SWB_MAX_SHAPE_VERTS * 2 : NULL);
 }
 
 /* environment.py:88-108 Environment.step for env range [i0, i1).
@@ -802,6 +836,7 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
       for (int s = 0; s < S; ++s) { x[s] = e->p_x[en * S + s]; y[s] = e->p_y[en * S + s]; }
       e->step_count[i] = 0;
       e->reset_next[i] = 0;
+      if (e->ov_flag) e->ov_flag[i] = 0;                 /* fresh sprites: the setters' effects end with the episode */
       observe(e, i, obs, success ? success + i : NULL, error ? error + i : NULL, NULL);
       if (reward) reward[i] = NAN;                       /* dm_env.restart: reward None */
       if (discount) discount[i] = NAN;
@@ -809,8 +844,6 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
       continue;
     }
     const int en = e->entry[i], n = e->n[i];
-    const int32_t* shape = e->p_shape + en * S;
-    const double *scale = e->p_scale + en * S, *ca = e->p_ca + en * S, *sa = e->p_sa + en * S;
     e->step_count[i] += 1;                               /* :93 */
     double cost = 0.0;
     float cost_f32 = 0.0f;
@@ -830,7 +863,7 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
               tx = (double)((float)x[body] - (float)x[s]);
               ty = (double)((float)y[body] - (float)y[s]);
             } else { tx = x[body] - x[s]; ty = y[body] - y[s]; }
-            const int nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+            const int nv = env_path(e, i, s, cx, cy);
             if (point_in_centered_path(nv, cx, cy, tx, ty)) {
               x[s] = move1(c->pos_is_f32, x[s], m0, c->keep_in_frame);
               y[s] = move1(c->pos_is_f32, y[s], m1, c->keep_in_frame);
@@ -854,7 +887,7 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
         double tx, ty;
         if (c->pos_is_f32) { tx = (double)(a[0] - (float)x[s]); ty = (double)(a[1] - (float)y[s]); }
         else { tx = (double)a[0] - x[s]; ty = (double)a[1] - y[s]; }
-        const int nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+        const int nv = env_path(e, i, s, cx, cy);
         if (point_in_centered_path(nv, cx, cy, tx, ty)) {
           x[s] = move1(c->pos_is_f32, x[s], (double)m0f, c->keep_in_frame);
           y[s] = move1(c->pos_is_f32, y[s], (double)m1f, c->keep_in_frame);
@@ -877,7 +910,7 @@ int swo_step_range(swo_engine* e, int i0, int i1, const void* actions, uint8_t* 
       }
       for (int s = n - 1; s >= 0; --s) {                 /* sprites[::-1] :77-81 */
         const double tx = a[0] - x[s], ty = a[1] - y[s]; /* f64 - f32 -> f64 */
-        const int nv = centered_path(shape[s], scale[s], ca[s], sa[s], cx, cy);
+        const int nv = env_path(e, i, s, cx, cy);
         if (point_in_centered_path(nv, cx, cy, tx, ty)) {
           x[s] = move1(c->pos_is_f32, x[s], m0, c->keep_in_frame);
           y[s] = move1(c->pos_is_f32, y[s], m1, c->keep_in_frame);
@@ -942,10 +975,96 @@ int swo_set_positions(swo_engine* e, const double* x, const double* y) {
   return 0;
 }
 
+/* sprite.py:152-175 attribute setters on the live sprite `sprite` of environment `env` (same contract as
+ * swb_set_sprite_attr, include/swb.h).  matplotlib arithmetic: Affine2D.rotate(theta) = [[a,-b],[b,a]] with
+ * a = math.cos(theta), b = math.sin(theta), theta = math.radians(deg) = deg * (pi / 180); Affine2D.scale(f) =
+ * diag(f, f); transform_path -> _path.h affine_transform_2d (t0 = sx*x; t1 = shx*y; t0 + t1 + tx; no FMA). */
+static void affine2(double sx, double shx, double shy, double sy, int n, const double* in, double* out) {
+  for (int i = 0; i < n; ++i) {
+    const double x = in[2 * i], y = in[2 * i + 1];
+    double t0 = sx * x, t1 = shx * y;
+    const double ox = t0 + t1 + 0.0;
+    t0 = shy * x; t1 = sy * y;
+    out[2 * i] = ox;
+    out[2 * i + 1] = t0 + t1 + 0.0;
+  }
+}
+
+int swo_set_sprite_attr(swo_engine* e, int env, int sprite, int attr, double value, const double* delta, const int8_t* label) {
+  const swb_config* c = &e->cfg;
+  const int N = c->n_envs, S = c->max_sprites, T = c->n_tasks;
+  if (env < 0 || env >= N || e->episode[env] == 0 || e->reset_next[env]) return -1;
+  if (sprite < 0 || sprite >= e->n[env]) return -1;
+  if (!e->ov_flag) {
+    e->ov_flag = calloc(N, 1);
+    e->ov_shape = calloc((size_t)N * S, sizeof(int32_t));
+    e->ov_scale = calloc((size_t)N * S, sizeof(double));
+    e->ov_angle = calloc((size_t)N * S, sizeof(double));
+    e->ov_cpath = calloc((size_t)N * S * SWB_MAX_SHAPE_VERTS * 2, sizeof(double));
+    e->ov_label = calloc((size_t)N * T * S, 1);
+  }
+  const int en = e->entry[env];
+  if (!e->ov_flag[env]) {                              /* materialise the episode's sprites from the pool */
+    if (!e->p_angle) return -2;
+    double cx[SWB_MAX_SHAPE_VERTS], cy[SWB_MAX_SHAPE_VERTS];
+    for (int s = 0; s < e->n[env]; ++s) {
+      const int nv = env_path(e, env, s, cx, cy);
+      double* q = e->ov_cpath + ((size_t)env * S + s) * SWB_MAX_SHAPE_VERTS * 2;
+      for (int k = 0; k < nv; ++k) { q[2 * k] = cx[k]; q[2 * k + 1] = cy[k]; }
+      e->ov_shape[env * S + s] = e->p_shape[en * S + s];
+      e->ov_scale[env * S + s] = e->p_scale[en * S + s];
+      e->ov_angle[env * S + s] = e->p_angle[en * S + s];
+    }
+    memcpy(e->ov_label + (size_t)env * T * S, e->p_label + (size_t)en * T * S, (size_t)T * S);
+    e->ov_flag[env] = 1;
+  }
+  double* path = e->ov_cpath + ((size_t)env * S + sprite) * SWB_MAX_SHAPE_VERTS * 2;
+  double out[SWB_MAX_SHAPE_VERTS * 2];
+  const int o = env * S + sprite;
+  int nv = g_off[e->ov_shape[o] + 1] - g_off[e->ov_shape[o]];
+  if (attr == SWB_ATTR_SHAPE) {                        /* :152-155 _shape = s; _reset_centered_path() */
+    const int sh = (int)value;
+    if (sh < 0 || sh >= g_nshapes) return -1;
+    const double th = e->ov_angle[o] * (3.14159265358979323846 / 180.0), ca = cos(th), sa = sin(th), sc = e->ov_scale[o];
+    nv = g_off[sh + 1] - g_off[sh];
+    affine2(ca * sc, -sa * sc, sa * sc, ca * sc, nv, g_verts + 2 * g_off[sh], out);
+    e->ov_shape[o] = sh;
+  } else if (attr == SWB_ATTR_ANGLE) {                 /* :161-165 rotate_deg(a - self._angle) on the current path */
+    const double d = delta ? *delta : value - e->ov_angle[o];
+    const double th = d * (3.14159265358979323846 / 180.0), ca = cos(th), sa = sin(th);
+    affine2(ca, -sa, sa, ca, nv, path, out);
+    e->ov_angle[o] = value;
+  } else if (attr == SWB_ATTR_SCALE) {                 /* :171-175 scale(s - self._scale): the difference, as the reference does */
+    const double f = delta ? *delta : value - e->ov_scale[o];
+    affine2(f, 0.0, 0.0, f, nv, path, out);
+    e->ov_scale[o] = value;
+  } else {
+    return -1;
+  }
+  memcpy(path, out, sizeof(double) * 2 * nv);
+  if (label) for (int t = 0; t < T; ++t) e->ov_label[((size_t)env * T + t) * S + sprite] = label[t];
+  return 0;
+}
+
+/* The sprite as the oracle currently sees it (shape index, angle, scale, centred path). */
+int swo_get_sprite(swo_engine* e, int env, int sprite, int32_t* shape, double* angle, double* scale, int32_t* n_verts, double* path_xy) {
+  const int S = e->cfg.max_sprites, en = e->entry[env];
+  if (env < 0 || env >= e->cfg.n_envs || sprite < 0 || sprite >= e->n[env]) return -1;
+  const int ov = e->ov_flag && e->ov_flag[env];
+  double cx[SWB_MAX_SHAPE_VERTS], cy[SWB_MAX_SHAPE_VERTS];
+  const int nv = env_path(e, env, sprite, cx, cy);
+  if (shape) *shape = ov ? e->ov_shape[env * S + sprite] : e->p_shape[en * S + sprite];
+  if (angle) *angle = ov ? e->ov_angle[env * S + sprite] : (e->p_angle ? e->p_angle[en * S + sprite] : 0.0);
+  if (scale) *scale = ov ? e->ov_scale[env * S + sprite] : e->p_scale[en * S + sprite];
+  if (n_verts) *n_verts = nv;
+  if (path_xy) for (int k = 0; k < nv; ++k) { path_xy[2 * k] = cx[k]; path_xy[2 * k + 1] = cy[k]; }
+  return 0;
+}
+
 /* Single frame without an engine (used by renderer parity tests). */
 int swo_render_sprites(const swb_config* cfg, int n, const double* x, const double* y,
                        const int32_t* shape, const double* scale, const double* ca, const double* sa,
                        const uint8_t* rgb, uint8_t* obs) {
-  render_env(cfg, n, x, y, shape, scale, ca, sa, rgb, obs);
+  render_env(cfg, n, x, y, shape, scale, ca, sa, rgb, obs, NULL);
   return 0;
 }

@@ -19,6 +19,8 @@ TERM_ALL, TERM_ANY = 0, 1
 STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 # enum swb_env_error
 ENV_ERR_DB_ZERO, ENV_ERR_DB_LABELS, ENV_ERR_SPAN_OVERFLOW = 1, 2, 4
+# enum swb_sprite_attr
+ATTR_SHAPE, ATTR_ANGLE, ATTR_SCALE = 0, 1, 2
 
 
 class SwbTask(C.Structure):

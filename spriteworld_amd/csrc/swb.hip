@@ -24,6 +24,11 @@ extern template __global__ void swb_step_kernel<10, 2, 8>(const swb_params);
 extern template __global__ void swb_step_kernel<20, 2, 6>(const swb_params);
 extern template __global__ void swb_step_kernel<20, 2, 8>(const swb_params);
 extern template __global__ void swb_step_kernel<20, 4, 8>(const swb_params);
+extern template __global__ void swb_step_kernel<4, 2, 8, true>(const swb_params);
+extern template __global__ void swb_step_kernel<10, 2, 8, true>(const swb_params);
+extern template __global__ void swb_step_kernel<20, 2, 6, true>(const swb_params);
+extern template __global__ void swb_step_kernel<20, 2, 8, true>(const swb_params);
+extern template __global__ void swb_step_kernel<20, 4, 8, true>(const swb_params);
 
 
 namespace {
@@ -89,6 +94,11 @@ struct swb_engine {
   uint8_t* d_reset_next = nullptr;
   uint32_t *d_ovf = nullptr, *d_ovf_bitmap = nullptr;
   int ovf_slots = 0;
+  // live sprite overrides (swb_set_sprite_attr), allocated at the first call
+  uint8_t* d_ov_flag = nullptr;
+  int32_t* d_ov_shape = nullptr;
+  double *d_ov_scale = nullptr, *d_ov_angle = nullptr, *d_ov_cpath = nullptr;
+  int8_t* d_ov_label = nullptr;
   // timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -100,13 +110,14 @@ namespace {
 
 typedef void (*kernel_fn)(const swb_params);
 
-struct variant { int nw, ncol, vs; kernel_fn fn; size_t lds_fixed, outrow_bytes; };
+struct variant { int nw, ncol, vs; kernel_fn fn, fn_ov; size_t lds_fixed, outrow_bytes; };
 
 template <int NW, int NCOL, int VS>
 variant make_variant() {
   // wave_lds<NW> + the output-row staging (3 bytes per pixel; never less than build_all_edges' 98 dwords of scratch)
   const size_t outrow = std::max<size_t>(392, (size_t)NCOL * 64 * 3);
-  return {NW, NCOL, VS, swb_step_kernel<NW, NCOL, VS>, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
+  return {NW, NCOL, VS, swb_step_kernel<NW, NCOL, VS>, swb_step_kernel<NW, NCOL, VS, true>,
+          (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
 }
 
 // canvas widths up to 32*NW pixels, image widths up to 64*NCOL pixels, up to VS output rows in
@@ -199,8 +210,10 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
   if (const char* x = getenv("SWB_EXTRA_LDS")) lds += (size_t)atoi(x);      // occupancy experiments only (tools/r02_occ.sh)
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
+  // engines on which a sprite setter has been called run the build that reads the per-environment overrides
+  const kernel_fn fn = h->d_ov_flag ? v->fn_ov : v->fn;
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(v->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (!h->d_ovf || (int)lds < h->ovf_lds_bytes) {      // first launch, or a new pool shrank the LDS footprint (more waves resident)
     if (h->d_ovf) {
       HIP_TRY(hipDeviceSynchronize());
@@ -218,7 +231,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL(v->fn, dim3(blocks), dim3(SWB_WAVE * SWB_WAVES_PER_BLOCK), lds, stream, p);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(SWB_WAVE * SWB_WAVES_PER_BLOCK), lds, stream, p);
   HIP_TRY(hipGetLastError());
   if (h->timing) {
     HIP_TRY(hipEventRecord(e1, stream));
@@ -304,7 +317,8 @@ int swb_destroy(swb_handle h) {
   void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
-                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler};
+                  h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler,
+                  h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;
@@ -694,6 +708,203 @@ int swb_set_positions(swb_handle h, const double* x_host, const double* y_host, 
   const size_t NS = (size_t)h->p.N * h->p.S;
   HIP_TRY(hipMemcpy(h->d_x, x_host, NS * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_y, y_host, NS * 8, hipMemcpyHostToDevice));
+  return SWB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sprite attribute setters (sprite.py:152-175).  The arithmetic is matplotlib's, restated on the host:
+//   Affine2D.rotate(theta)   -> [[a, -b, 0], [b, a, 0]] with a = cos(theta), b = sin(theta)   (transforms.py)
+//   Affine2D.scale(s)        -> [[s, 0, 0], [0, s, 0]]
+//   transform_path           -> _path.h affine_transform_2d: t0 = sx*x; t1 = shx*y; x' = t0 + t1 + tx  (no FMA;
+//                               this file is compiled with -ffp-contract=off)
+// ---------------------------------------------------------------------------------------------------
+static void affine2(double sx, double shx, double shy, double sy, int n, const double* in, double* out) {
+  for (int i = 0; i < n; ++i) {
+    const double x = in[2 * i], y = in[2 * i + 1];
+    double t0 = sx * x, t1 = shx * y;
+    const double ox = t0 + t1 + 0.0;
+    t0 = shy * x; t1 = sy * y;
+    out[2 * i] = ox;
+    out[2 * i + 1] = t0 + t1 + 0.0;
+  }
+}
+static double deg2rad(double d) { return d * (3.14159265358979323846 / 180.0); }   // math.radians
+
+int swb_sprite_path_op(int32_t attr, double a, double b, int32_t n, const double* in_xy, double* out_xy) {
+  if (!in_xy || !out_xy || n < 0) return fail(SWB_ERR_INVALID, "bad argument");
+  if (attr == SWB_ATTR_SHAPE) {          // _reset_centered_path: scale(a) then rotate_deg(b): M = R * S
+    const double th = deg2rad(b), ca = std::cos(th), sa = std::sin(th);
+    affine2(ca * a, -sa * a, sa * a, ca * a, n, in_xy, out_xy);
+  } else if (attr == SWB_ATTR_ANGLE) {   // rotate_deg(a - b)
+    const double th = deg2rad(a - b), ca = std::cos(th), sa = std::sin(th);
+    affine2(ca, -sa, sa, ca, n, in_xy, out_xy);
+  } else if (attr == SWB_ATTR_SCALE) {   // scale(a - b): the reference's setter scales by the DIFFERENCE (sprite.py:173)
+    const double f = a - b;
+    affine2(f, 0.0, 0.0, f, n, in_xy, out_xy);
+  } else {
+    return fail(SWB_ERR_INVALID, "unknown sprite attribute %d", attr);
+  }
+  return SWB_OK;
+}
+
+namespace {
+
+// Host copy of one environment's override record.
+struct env_override {
+  std::vector<int32_t> shape;
+  std::vector<double> scale, angle, cpath;   // cpath: [S][SWB_MAX_SHAPE_VERTS][2]
+  std::vector<int8_t> label;                 // [T][S]
+};
+
+int ov_allocate(swb_engine* h) {
+  if (h->d_ov_flag) return 0;
+  const size_t N = h->p.N, NS = N * h->p.S, T = h->p.n_tasks;
+  int rc = 0;
+  rc |= upload<int32_t>(&h->d_ov_shape, nullptr, NS);
+  rc |= upload<double>(&h->d_ov_scale, nullptr, NS);
+  rc |= upload<double>(&h->d_ov_angle, nullptr, NS);
+  rc |= upload<int8_t>(&h->d_ov_label, nullptr, NS * T);
+  rc |= upload<double>(&h->d_ov_cpath, nullptr, NS * SWB_MAX_SHAPE_VERTS * 2);
+  rc |= upload<uint8_t>(&h->d_ov_flag, nullptr, N);       // last: its presence switches the engine to the OV kernels
+  if (rc) return SWB_ERR_HIP;
+  swb_params& p = h->p;
+  p.ov_flag = h->d_ov_flag; p.ov_shape = h->d_ov_shape; p.ov_scale = h->d_ov_scale; p.ov_angle = h->d_ov_angle;
+  p.ov_label = h->d_ov_label; p.ov_cpath = h->d_ov_cpath;
+  return 0;
+}
+
+// The record of environment `env`: its override arrays when the flag is set, else built from its pool entry
+// (fresh centred paths, sprite.py:96-101).  `n` receives the episode's sprite count.
+int ov_fetch(swb_engine* h, int env, env_override* r, int* n, bool* was_set) {
+  const int S = h->p.S, T = h->p.n_tasks;
+  r->shape.assign(S, 0); r->scale.assign(S, 1.0); r->angle.assign(S, 0.0);
+  r->cpath.assign((size_t)S * SWB_MAX_SHAPE_VERTS * 2, 0.0); r->label.assign((size_t)T * S, 0);
+  uint8_t flag = 0, rn = 0;
+  int32_t en = 0, ns = 0;
+  if (h->d_ov_flag) HIP_TRY(hipMemcpy(&flag, h->d_ov_flag + env, 1, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&rn, h->d_reset_next + env, 1, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&en, h->d_entry + env, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&ns, h->d_nspr + env, 4, hipMemcpyDeviceToHost));
+  int32_t ep = 0;
+  HIP_TRY(hipMemcpy(&ep, h->d_episode + env, 4, hipMemcpyDeviceToHost));
+  if (ep == 0) return fail(SWB_ERR_STATE, "environment %d has not been reset yet: it has no sprites", env);
+  if (rn) return fail(SWB_ERR_STATE, "environment %d is about to reset (its episode ended): its sprites are gone at the next step", env);
+  *n = ns;
+  *was_set = flag != 0;
+  const size_t o = (size_t)env * S, pe = (size_t)en * S;
+  if (flag) {
+    HIP_TRY(hipMemcpy(r->shape.data(), h->d_ov_shape + o, S * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r->scale.data(), h->d_ov_scale + o, S * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r->angle.data(), h->d_ov_angle + o, S * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r->label.data(), h->d_ov_label + o * T, (size_t)T * S, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r->cpath.data(), h->d_ov_cpath + o * SWB_MAX_SHAPE_VERTS * 2, (size_t)S * SWB_MAX_SHAPE_VERTS * 16,
+                      hipMemcpyDeviceToHost));
+    return 0;
+  }
+  if (!h->p.p_angle) return fail(SWB_ERR_STATE, "the pool carries no angle column (swb_pool.angle)");
+  std::vector<double> ca(S), sa(S);
+  HIP_TRY(hipMemcpy(r->shape.data(), h->d_p_shape + pe, S * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(r->scale.data(), h->d_p_scale + pe, S * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(r->angle.data(), h->d_p_angle + pe, S * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ca.data(), h->d_p_ca + pe, S * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sa.data(), h->d_p_sa + pe, S * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(r->label.data(), h->d_p_label + pe * T, (size_t)T * S, hipMemcpyDeviceToHost));
+  std::vector<double> sv((size_t)h->p.max_verts * 2 + 2);
+  std::vector<int32_t> off(h->shape_nverts.size() + 1);
+  HIP_TRY(hipMemcpy(off.data(), h->d_shape_off, off.size() * 4, hipMemcpyDeviceToHost));
+  for (int s2 = 0; s2 < ns; ++s2) {
+    const int sh = r->shape[s2];
+    if (sh < 0 || sh >= (int)h->shape_nverts.size()) return fail(SWB_ERR_STATE, "pool entry %d uses shape %d", en, sh);
+    const int nv = h->shape_nverts[sh];
+    HIP_TRY(hipMemcpy(sv.data(), h->d_shape_verts + 2 * (size_t)off[sh], (size_t)nv * 16, hipMemcpyDeviceToHost));
+    // the kernel's centered_vertex with the pool's cos / sin (math.cos(math.radians(angle)), computed by the caller)
+    affine2(ca[s2] * r->scale[s2], -sa[s2] * r->scale[s2], sa[s2] * r->scale[s2], ca[s2] * r->scale[s2], nv, sv.data(),
+            r->cpath.data() + (size_t)s2 * SWB_MAX_SHAPE_VERTS * 2);
+  }
+  return 0;
+}
+
+int ov_store(swb_engine* h, int env, const env_override& r) {
+  const int S = h->p.S, T = h->p.n_tasks;
+  const size_t o = (size_t)env * S;
+  HIP_TRY(hipMemcpy(h->d_ov_shape + o, r.shape.data(), S * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_ov_scale + o, r.scale.data(), S * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_ov_angle + o, r.angle.data(), S * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_ov_label + o * T, r.label.data(), (size_t)T * S, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_ov_cpath + o * SWB_MAX_SHAPE_VERTS * 2, r.cpath.data(), (size_t)S * SWB_MAX_SHAPE_VERTS * 16,
+                    hipMemcpyHostToDevice));
+  const uint8_t one = 1;
+  HIP_TRY(hipMemcpy(h->d_ov_flag + env, &one, 1, hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace
+
+int swb_set_sprite_attr(swb_handle h, int32_t env, int32_t sprite, int32_t attr, double value, const double* delta,
+                        const int8_t* label, void* stream) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  if (!h->have_pool || !h->have_shapes) return fail(SWB_ERR_STATE, "no pool / shape table installed");
+  if (env < 0 || env >= h->p.N) return fail(SWB_ERR_INVALID, "environment %d out of range", env);
+  if (attr < SWB_ATTR_SHAPE || attr > SWB_ATTR_SCALE) return fail(SWB_ERR_INVALID, "unknown sprite attribute %d", attr);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  env_override r;
+  int n = 0;
+  bool was_set = false;
+  if (int rc = ov_fetch(h, env, &r, &n, &was_set)) return rc;
+  if (sprite < 0 || sprite >= n) return fail(SWB_ERR_INVALID, "environment %d has %d sprites: sprite %d out of range", env, n, sprite);
+  const int S = h->p.S, T = h->p.n_tasks;
+  double* path = r.cpath.data() + (size_t)sprite * SWB_MAX_SHAPE_VERTS * 2;
+  const int nv_old = h->shape_nverts[r.shape[sprite]];
+  std::vector<double> out((size_t)SWB_MAX_SHAPE_VERTS * 2, 0.0);
+  if (attr == SWB_ATTR_SHAPE) {                        // sprite.py:152-155: _shape = s; _reset_centered_path()
+    const int sh = (int)value;
+    if ((double)sh != value || sh < 0 || sh >= (int)h->shape_nverts.size()) return fail(SWB_ERR_INVALID, "bad shape index %g", value);
+    const int nv = h->shape_nverts[sh];
+    std::vector<int32_t> off(h->shape_nverts.size() + 1);
+    HIP_TRY(hipMemcpy(off.data(), h->d_shape_off, off.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<double> sv((size_t)nv * 2);
+    HIP_TRY(hipMemcpy(sv.data(), h->d_shape_verts + 2 * (size_t)off[sh], (size_t)nv * 16, hipMemcpyDeviceToHost));
+    if (int rc = swb_sprite_path_op(SWB_ATTR_SHAPE, r.scale[sprite], r.angle[sprite], nv, sv.data(), out.data())) return rc;
+    r.shape[sprite] = sh;
+  } else if (attr == SWB_ATTR_ANGLE) {                 // :161-165: rotate_deg(a - _angle) applied to the current path
+    const double a = delta ? *delta : value, b = delta ? 0.0 : r.angle[sprite];
+    if (int rc = swb_sprite_path_op(SWB_ATTR_ANGLE, a, b, nv_old, path, out.data())) return rc;
+    r.angle[sprite] = value;
+  } else {                                             // :171-175: scale(s - _scale) applied to the current path
+    const double a = delta ? *delta : value, b = delta ? 0.0 : r.scale[sprite];
+    if (int rc = swb_sprite_path_op(SWB_ATTR_SCALE, a, b, nv_old, path, out.data())) return rc;
+    r.scale[sprite] = value;
+  }
+  memcpy(path, out.data(), out.size() * sizeof(double));
+  if (label) for (int t = 0; t < T; ++t) r.label[(size_t)t * S + sprite] = label[t];
+  // LDS of a wave is sized by the most polygon vertices an episode can have: a new shape may raise it
+  int tot = 0;
+  for (int s2 = 0; s2 < n; ++s2) tot += h->shape_nverts[r.shape[s2]];
+  h->p.max_edges = std::max(h->p.max_edges, (tot + 3) & ~3);
+  if (int rc = ov_allocate(h)) return rc;
+  (void)was_set;
+  return ov_store(h, env, r);
+}
+
+int swb_get_sprite(swb_handle h, int32_t env, int32_t sprite, int32_t* shape, double* angle, double* scale, int32_t* n_verts,
+                   double* path_xy, void* stream) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  if (!h->have_pool || !h->have_shapes) return fail(SWB_ERR_STATE, "no pool / shape table installed");
+  if (env < 0 || env >= h->p.N) return fail(SWB_ERR_INVALID, "environment %d out of range", env);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  env_override r;
+  int n = 0;
+  bool was_set = false;
+  if (int rc = ov_fetch(h, env, &r, &n, &was_set)) return rc;
+  if (sprite < 0 || sprite >= n) return fail(SWB_ERR_INVALID, "environment %d has %d sprites: sprite %d out of range", env, n, sprite);
+  const int nv = h->shape_nverts[r.shape[sprite]];
+  if (shape) *shape = r.shape[sprite];
+  if (angle) *angle = r.angle[sprite];
+  if (scale) *scale = r.scale[sprite];
+  if (n_verts) *n_verts = nv;
+  if (path_xy) memcpy(path_xy, r.cpath.data() + (size_t)sprite * SWB_MAX_SHAPE_VERTS * 2, (size_t)nv * 16);
   return SWB_OK;
 }
 

@@ -14,3 +14,9 @@ template __global__ void swb_step_kernel<10, 2, 8>(const swb_params);
 template __global__ void swb_step_kernel<20, 2, 6>(const swb_params);
 template __global__ void swb_step_kernel<20, 2, 8>(const swb_params);
 template __global__ void swb_step_kernel<20, 4, 8>(const swb_params);
+// ... and their builds with live sprite overrides (swb_set_sprite_attr)
+template __global__ void swb_step_kernel<4, 2, 8, true>(const swb_params);
+template __global__ void swb_step_kernel<10, 2, 8, true>(const swb_params);
+template __global__ void swb_step_kernel<20, 2, 6, true>(const swb_params);
+template __global__ void swb_step_kernel<20, 2, 8, true>(const swb_params);
+template __global__ void swb_step_kernel<20, 4, 8, true>(const swb_params);

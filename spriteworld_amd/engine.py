@@ -160,6 +160,22 @@ class Engine(object):
     y = np.ascontiguousarray(y, dtype=np.float64)
     _lib.check(self.lib.swb_set_positions(self._h, _ptr(x), _ptr(y), self._stream()))
 
+  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
+    """sprite.py:152-175 setters on a live sprite (swb_set_sprite_attr; attr: _abi.ATTR_SHAPE / ATTR_ANGLE / ATTR_SCALE)."""
+    d = None if delta is None else C.byref(C.c_double(float(delta)))
+    lab = None if label is None else np.ascontiguousarray(label, dtype=np.int8)
+    _lib.check(self.lib.swb_set_sprite_attr(self._h, int(env), int(sprite), int(attr), float(value), d, _ptr(lab),
+                                            self._stream()))
+
+  def get_sprite(self, env, sprite):
+    """dict(shape=index, angle, scale, path=f64[n,2]): the sprite as the engine currently sees it (swb_get_sprite)."""
+    shape, nv = C.c_int32(0), C.c_int32(0)
+    angle, scale = C.c_double(0.0), C.c_double(0.0)
+    path = np.zeros((_abi.SWB_MAX_SHAPE_VERTS, 2), dtype=np.float64)
+    _lib.check(self.lib.swb_get_sprite(self._h, int(env), int(sprite), C.byref(shape), C.byref(angle), C.byref(scale),
+                                       C.byref(nv), _ptr(path), self._stream()))
+    return {'shape': shape.value, 'angle': angle.value, 'scale': scale.value, 'path': path[:nv.value].copy()}
+
   def outputs_host(self):
     torch.cuda.synchronize(self.device)
     return {

@@ -273,6 +273,29 @@ class BatchedEnvironment(object):
   def sample_actions(self):
     return self._action_space.sample(self._num_envs)
 
+  # ------------------------------------------------------------------ live sprites (sprite.py:152-175)
+  def sprites(self, env=0):
+    """The sprites of environment `env` in its current episode, back to front, as `sprite.LiveSprite` handles
+    (the reference's `env.state()['sprites']`): `env.sprites(3)[0].angle = 45` acts on the device state."""
+    from spriteworld_amd import sprite as sprite_lib
+    n = int(self._engine.state()['n_sprites'][env])
+    return [sprite_lib.LiveSprite(self, env, k) for k in range(n)]
+
+  def set_sprite_attr(self, env, sprite, name, value):
+    """`sprites(env)[sprite].<name> = value` for name in ('shape', 'angle', 'scale'): the reference's setters
+    (sprite.py:152-175) through swb_set_sprite_attr.  The sprite's task labels are re-evaluated with the new
+    factor (tasks.py:134-137,196-205), so a filter keyed on shape / angle / scale follows the change."""
+    from spriteworld_amd import shapes as shapes_lib
+    from spriteworld_amd import sprite as sprite_lib
+    attr = {'shape': _abi.ATTR_SHAPE, 'angle': _abi.ATTR_ANGLE, 'scale': _abi.ATTR_SCALE}[name]
+    live = sprite_lib.LiveSprite(self, env, sprite)
+    factors = live.factors
+    factors[name] = value
+    proxy = collections.namedtuple('_Factors', ['factors'])(factors)
+    label = np.array([lowering._label_of(sub, proxy) for sub in lowering.subtasks_of(self._task)], dtype=np.int8)  # pylint: disable=protected-access
+    self._engine.set_sprite_attr(env, sprite, attr, shapes_lib.shape_index(value) if name == 'shape' else float(value),
+                                 label=label)
+
   def close(self):
     self._engine.close()
 
@@ -385,6 +408,12 @@ class Environment(object):
 
   def state(self):
     return self._batched.state()
+
+  @property
+  def sprites(self):
+    """The current episode's sprites (reference: `env.state()['sprites']`) as `sprite.LiveSprite` handles whose
+    shape / angle / scale can be assigned like on the reference's Sprite (sprite.py:152-175)."""
+    return self._batched.sprites(0)
 
   def close(self):
     self._batched.close()

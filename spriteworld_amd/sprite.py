@@ -7,6 +7,11 @@ carries the ten factors from `init_sprites()` to `lowering.lower_episodes`, whic
 also accepts the reference's own Sprite objects (duck-typed on the same
 attribute names).  Geometry (centred path, vertices, contains_point) lives in
 the HIP kernels, not here.
+
+`LiveSprite` is the handle on a sprite of a RUNNING environment: its attribute
+setters are the reference's (:152-175 -- shape resets the centred path, angle
+and scale transform it incrementally, scale by the DIFFERENCE (s - old)) and act
+on the device state through `swb_set_sprite_attr`.
 """
 import collections
 
@@ -50,3 +55,73 @@ class Sprite(object):
   @property
   def factors(self):
     return collections.OrderedDict((name, getattr(self, name)) for name in FACTOR_NAMES)
+
+
+class LiveSprite(object):
+  """Sprite `index` of environment `env` of a running engine, in its current episode.
+
+  Read access mirrors the reference's properties (sprite.py:140-214); `shape`, `angle` and `scale` can be
+  assigned exactly like on the reference's Sprite (sprite.py:152-175): the change shows in the next
+  observation(), hit-test and SpriteFactors read, and ends with the episode (a reset draws fresh sprites).
+  The colour and velocity setters of the reference (:177-214) do not exist here: those factors are static
+  columns of the episode pool."""
+
+  def __init__(self, environment, env, index):
+    self._environment, self._env, self._index = environment, int(env), int(index)
+
+  def _read(self):
+    return self._environment.engine.get_sprite(self._env, self._index)
+
+  def _factor_row(self):
+    return self._environment.engine.factors()[self._env, self._index].cpu().numpy()
+
+  x = property(lambda self: self._factor_row()[0])
+  y = property(lambda self: self._factor_row()[1])
+  c0 = property(lambda self: self._factor_row()[5])
+  c1 = property(lambda self: self._factor_row()[6])
+  c2 = property(lambda self: self._factor_row()[7])
+  x_vel = property(lambda self: self._factor_row()[8])
+  y_vel = property(lambda self: self._factor_row()[9])
+  position = property(lambda self: self._factor_row()[:2])
+  color = property(lambda self: tuple(self._factor_row()[5:8]))
+  velocity = property(lambda self: tuple(self._factor_row()[8:10]))
+
+  @property
+  def shape(self):
+    return shapes.SHAPE_NAMES[self._read()['shape']]
+
+  @shape.setter
+  def shape(self, s):
+    if s not in shapes.SHAPES:
+      raise KeyError(s)
+    self._environment.set_sprite_attr(self._env, self._index, 'shape', s)
+
+  @property
+  def angle(self):
+    return self._read()['angle']
+
+  @angle.setter
+  def angle(self, a):
+    self._environment.set_sprite_attr(self._env, self._index, 'angle', a)
+
+  @property
+  def scale(self):
+    return self._read()['scale']
+
+  @scale.setter
+  def scale(self, s):
+    self._environment.set_sprite_attr(self._env, self._index, 'scale', s)
+
+  @property
+  def vertices(self):
+    """sprite.py:128-133: the centred path translated by the position ((1*x + 0*y) + px, as matplotlib does)."""
+    path = self._read()['path']
+    pos = self._factor_row()[:2]
+    return np.stack([1.0 * path[:, 0] + 0.0 * path[:, 1] + pos[0], 0.0 * path[:, 0] + 1.0 * path[:, 1] + pos[1]], axis=1)
+
+  @property
+  def factors(self):
+    row = self._factor_row()
+    d = collections.OrderedDict(zip(FACTOR_NAMES, row.tolist()))
+    d['shape'] = shapes.SHAPE_NAMES[int(row[2]) - 1]
+    return d
