@@ -75,6 +75,33 @@ def main():
         run(name, aa, p, PMC_LAUNCHES - 2, 2, False)
         order.append([name, aa, p, PMC_LAUNCHES])
     json.dump(order, open(sys.argv[2], 'w'))
+  elif mode == 'pmc-json':
+    # per-dispatch averages of every counter, per (workload, phase) group, as JSON on stdout
+    import sqlite3
+    order = json.load(open(sys.argv[2]))
+    out = {}
+    for db in sys.argv[3:]:
+      cur = sqlite3.connect(db).cursor()
+      rows = list(cur.execute("select dispatch_id, counter_name, value from counters_collection "
+                              "where kernel_name like '%swb_step%' order by dispatch_id"))
+      ids = sorted(set(r[0] for r in rows))
+      if len(ids) != sum(o[3] for o in order):
+        print('dispatch count mismatch in %s: %d vs %d' % (db, len(ids), sum(o[3] for o in order)), file=sys.stderr)
+        continue
+      group, k = {}, 0
+      for gi, o in enumerate(order):
+        for j in range(o[3]):
+          if j >= 4:
+            group[ids[k]] = gi
+          k += 1
+      acc = {}
+      for did, cname, val in rows:
+        if did in group:
+          acc.setdefault((group[did], cname), []).append(val)
+      for (gi, cname), vals in acc.items():
+        o = order[gi]
+        out.setdefault('%s:%d:%d' % (o[0], o[1], o[2]), {})[cname] = float(np.mean(vals))
+    print(json.dumps(out, indent=1))
   elif mode == 'pmc-report':
     import sqlite3
     order = json.load(open(sys.argv[2]))
