@@ -2,7 +2,8 @@
 
 Imports `/root/reference/spriteworld` read-only under the three shims SURVEY.md
 §8c / Appendix B pins:
-  1. `oracle/compat/dm_env`           -- dm_env is not installed in this image;
+  1. `oracle/compat/dm_env`           -- dm_env is not installed in this image (likewise `oracle/compat/absl`,
+                                         which only the reference's example_run_loop.py imports);
   2. `PIL.Image.ANTIALIAS = LANCZOS`  -- alias removed in Pillow 10, used at
                                          spriteworld/renderers/pil_renderer.py:84;
   3. `np.cast[dtype]` shim            -- removed in numpy 2, used at
@@ -45,8 +46,10 @@ def load_reference():
   # not shadow this repository's.
   try:
     import dm_env  # noqa: F401  (a real dm_env wins if one is ever installed)
+    import absl  # noqa: F401    (only the reference's example_run_loop.py needs it)
   except ImportError:
-    sys.path.append(_COMPAT)
+    if _COMPAT not in sys.path:
+      sys.path.append(_COMPAT)
   if REFERENCE_ROOT not in sys.path:
     sys.path.append(REFERENCE_ROOT)
   import spriteworld

@@ -1,0 +1,112 @@
+"""The reference's own `example_run_loop.py` (BASELINE configs[0]; example_run_loop.py:62-80) driving the drop-in.
+
+`main()` of the UNMODIFIED script runs twice in this process on the reference's shipped config module
+(`spriteworld.configs.cobra.goal_finding_new_position`): once as shipped, once with its `environment` symbol
+pointing at `spriteworld_amd.environment` -- the one-line change INTEGRATION.md describes.  The reference's
+config dict (its task / action-space / renderer / generator objects) goes unchanged into
+`spriteworld_amd.environment.Environment`, is lowered and stepped through the engine interface; the per-episode
+log lines (success, mean reward) and every time step must be identical.
+
+Where this container has no GPU the engine behind the interface is tests/_fake_engine.py (the CPU oracle with the
+engine's method surface); the HIP engine is compared with the same oracle bit for bit by the `-m gpu` tests.
+/root/reference does not exist on the GPU box, so the two halves cannot meet in one process anywhere.
+"""
+import copy
+import importlib
+import logging
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from oracle import ref_harness
+
+pytestmark = pytest.mark.skipif(not ref_harness.reference_available(), reason='reference tree not present')
+
+CONFIG = 'spriteworld.configs.cobra.goal_finding_new_position'
+N_EPISODES = 6
+
+
+class _Log(logging.Handler):
+
+  def __init__(self):
+    logging.Handler.__init__(self)
+    self.lines = []
+
+  def emit(self, record):
+    self.lines.append(record.getMessage())
+
+
+def _run_main(monkeypatch, run_loop, episodes, use_dropin, steps):
+  """One call of example_run_loop.main() with init_sprites replaying `episodes` (no numpy draws, so that the
+  RandomAgent's np.random stream is the same in both runs) and every time step recorded."""
+  from spriteworld import environment as ref_environment
+  from spriteworld_amd import environment as amd_environment
+  real = importlib.import_module(CONFIG)
+  it = iter(())
+
+  def get_config(mode):
+    nonlocal it
+    config = real.get_config(mode)
+    if use_dropin:        # the drop-in draws its pool up front: episode k is the k-th call
+      it = (copy.deepcopy(e) for e in episodes)
+    else:                 # the reference's constructor calls init_sprites() once itself (environment.py:68)
+      it = (copy.deepcopy(e) for e in [episodes[0]] + episodes)
+    config['init_sprites'] = lambda: next(it)
+    config['max_episode_length'] = 25
+    return config
+
+  fake_module = types.ModuleType('replayed_config')
+  fake_module.get_config = get_config
+  monkeypatch.setitem(sys.modules, 'replayed_config', fake_module)
+  run_loop.FLAGS.config = 'replayed_config'
+  run_loop.FLAGS.mode = 'train'
+  run_loop.FLAGS.num_episodes = N_EPISODES
+
+  env_module = amd_environment if use_dropin else ref_environment
+  base = env_module.Environment
+
+  class Recording(base):      # the loop's own Environment, with its time steps recorded
+
+    def __init__(self, **kwargs):
+      if use_dropin:
+        kwargs['episodes_per_pool'] = len(episodes)
+      base.__init__(self, **kwargs)
+
+    def step(self, action):
+      ts = base.step(self, action)
+      steps.append((int(ts.step_type), None if ts.reward is None else np.float64(ts.reward).view(np.uint64),
+                    bool(ts.observation['success']), ts.observation['image'].copy()))
+      return ts
+
+  shim = types.SimpleNamespace(Environment=Recording)
+  monkeypatch.setattr(run_loop, 'environment', shim)
+  handler = _Log()
+  logger = logging.getLogger('absl')
+  logger.addHandler(handler)
+  logger.setLevel(logging.INFO)
+  try:
+    np.random.seed(11)
+    run_loop.main([])
+  finally:
+    logger.removeHandler(handler)
+  return handler.lines
+
+
+def test_example_run_loop_main_drives_the_dropin(monkeypatch):
+  ref_harness.load_reference()
+  from spriteworld_amd import environment as amd_environment
+  from tests import _fake_engine
+  run_loop = importlib.import_module('example_run_loop')
+  monkeypatch.setattr(amd_environment._engine, 'Engine', _fake_engine.FakeEngine)
+  np.random.seed(5)
+  episodes = [importlib.import_module(CONFIG).get_config('train')['init_sprites']() for _ in range(N_EPISODES + 2)]
+  ref_steps, our_steps = [], []
+  ref_lines = _run_main(monkeypatch, run_loop, episodes, False, ref_steps)
+  our_lines = _run_main(monkeypatch, run_loop, episodes, True, our_steps)
+  assert len(ref_lines) == N_EPISODES and ref_lines == our_lines
+  assert len(ref_steps) == len(our_steps) > N_EPISODES
+  for t, (a, b) in enumerate(zip(ref_steps, our_steps)):
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], t
+    assert np.array_equal(a[3], b[3]), t
