@@ -63,8 +63,7 @@ class LiveSprite(object):
   Read access mirrors the reference's properties (sprite.py:140-214); `shape`, `angle` and `scale` can be
   assigned exactly like on the reference's Sprite (sprite.py:152-175): the change shows in the next
   observation(), hit-test and SpriteFactors read, and ends with the episode (a reset draws fresh sprites).
-  The colour and velocity setters of the reference (:177-214) do not exist here: those factors are static
-  columns of the episode pool."""
+  Position, colour and velocity are read-only properties, as in the reference (:140-204)."""
 
   def __init__(self, environment, env, index):
     self._environment, self._env, self._index = environment, int(env), int(index)
