@@ -196,6 +196,66 @@ def cpu_baseline(name, aa, budget_s=12.0):
   return out
 
 
+def assemble_line(args, res, elapsed):
+  """The JSON line (without the extras / cpu_baseline blocks) from one timed run: `res` is gpu_run()'s result,
+  `elapsed` the max-over-ranks wall time of the timed region.  Pure host code (tests call it without a GPU)."""
+  total_envs = args.envs_per_gpu * args.gpus
+  value = total_envs * args.steps / elapsed
+  kernel_s = res['kernel_ms'] / 1e3 / max(res['launches'], 1)
+  achieved = res['a_bytes'] * args.envs_per_gpu / kernel_s / 1e9
+  facts, variant = res['facts'], res['variant']
+  image = '%dx%d' % (facts['image'][1], facts['image'][0])
+  counters = profiled_counters(args.workload, args.envs_per_gpu, args.aa, variant['build_id'])
+  roofline = {
+      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+      'frac': achieved / HBM_PEAK_GBS, 'frac_of_measured_copy_peak': achieved / 6290.0,
+      'traffic': counters['hbm_traffic_bytes_per_launch'] if counters else None,
+      'kernel': variant['kernel'], 'kernel_ms': kernel_s * 1e3,
+      'algorithmic_bytes_per_env_step': res['a_bytes'],
+      'lds_bytes_per_wave': variant['lds_bytes_per_wave'], 'waves_per_simd': variant['waves_per_simd'],
+      'build_id': variant['build_id'],
+  }
+  if counters:
+    # instruction side (SURVEY 8d asks for both): the kernel is bound by instruction issue, not by HBM
+    waves_per_simd_resident = counters.get('resident_waves_per_simd', variant['waves_per_simd'])
+    roofline['instructions'] = {
+        'insts_valu_per_wave': counters['insts_valu_per_wave'], 'insts_salu_per_wave': counters['insts_salu_per_wave'],
+        'insts_lds_per_wave': counters['insts_lds_per_wave'],
+        'valu_cycles_per_inst': VALU_CYCLES_PER_INST,
+        'valu_issue_frac': counters['active_inst_valu_per_wave'] * waves_per_simd_resident / counters['wave_cycles_per_wave'],
+        'source': counters['source'],
+    }
+  else:
+    roofline['instructions'] = None       # no committed PMC pass for this build / workload (see profiles/)
+  out = {
+      'metric': 'env-steps/sec (incl. %s RGB render) at %d envs' % (image, args.envs_per_gpu),
+      'value': value,
+      'unit': 'env-steps/s',
+      'n_gpus': args.gpus,
+      'steps': args.steps,
+      'warmup': args.warmup,
+      'ms_per_step': elapsed / args.steps * 1e3,
+      'higher_is_better': True,
+      'scaling': 'weak',
+      'vs_baseline': None,
+      'dtype': 'i32 fixed-point raster/resample + f64 state',
+      'data': 'synthetic',
+      'config': {
+          'workload': '%s: %d envs/GPU x %d sprites, %s, %s reward, %s PILRenderer anti_aliasing=%d, auto-reset from '
+                      'an HBM pool%s' % (args.workload, args.envs_per_gpu, facts['sprites'], facts['action_space'],
+                                         facts['task'], image, facts['anti_aliasing'],
+                                         ' (BASELINE configs[2])' if (args.workload, args.envs_per_gpu, args.aa) ==
+                                         (WORKLOAD, ENVS_PER_GPU, 5) else ''),
+          'envs_per_gpu': args.envs_per_gpu, 'sprites': facts['sprites'], 'image': facts['image'],
+          'anti_aliasing': facts['anti_aliasing'],
+          'parallelism': 'env-sharded x%d, no data-path collective' % args.gpus,
+      },
+      'roofline': roofline,
+      'env_errors': res['errors'],
+  }
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -255,60 +315,7 @@ def main():
       dist.destroy_process_group()
     return
 
-  total_envs = args.envs_per_gpu * args.gpus
-  value = total_envs * args.steps / elapsed
-  kernel_s = res['kernel_ms'] / 1e3 / max(res['launches'], 1)
-  achieved = res['a_bytes'] * args.envs_per_gpu / kernel_s / 1e9
-  facts, variant = res['facts'], res['variant']
-  image = '%dx%d' % (facts['image'][1], facts['image'][0])
-  counters = profiled_counters(args.workload, args.envs_per_gpu, args.aa, variant['build_id'])
-  roofline = {
-      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-      'frac': achieved / HBM_PEAK_GBS, 'frac_of_measured_copy_peak': achieved / 6290.0,
-      'traffic': counters['hbm_traffic_bytes_per_launch'] if counters else None,
-      'kernel': variant['kernel'], 'kernel_ms': kernel_s * 1e3,
-      'algorithmic_bytes_per_env_step': res['a_bytes'],
-      'lds_bytes_per_wave': variant['lds_bytes_per_wave'], 'waves_per_simd': variant['waves_per_simd'],
-      'build_id': variant['build_id'],
-  }
-  if counters:
-    # instruction side (SURVEY 8d asks for both): the kernel is bound by instruction issue, not by HBM
-    waves_per_simd_resident = counters.get('resident_waves_per_simd', variant['waves_per_simd'])
-    roofline['instructions'] = {
-        'insts_valu_per_wave': counters['insts_valu_per_wave'], 'insts_salu_per_wave': counters['insts_salu_per_wave'],
-        'insts_lds_per_wave': counters['insts_lds_per_wave'],
-        'valu_cycles_per_inst': VALU_CYCLES_PER_INST,
-        'valu_issue_frac': counters['active_inst_valu_per_wave'] * waves_per_simd_resident / counters['wave_cycles_per_wave'],
-        'source': counters['source'],
-    }
-  else:
-    roofline['instructions'] = None       # no committed PMC pass for this build / workload (see profiles/)
-  out = {
-      'metric': 'env-steps/sec (incl. %s RGB render) at %d envs' % (image, args.envs_per_gpu),
-      'value': value,
-      'unit': 'env-steps/s',
-      'n_gpus': args.gpus,
-      'steps': args.steps,
-      'warmup': args.warmup,
-      'ms_per_step': elapsed / args.steps * 1e3,
-      'higher_is_better': True,
-      'scaling': 'weak',
-      'vs_baseline': None,
-      'dtype': 'i32 fixed-point raster/resample + f64 state',
-      'data': 'synthetic',
-      'config': {
-          'workload': '%s: %d envs/GPU x %d sprites, %s, %s reward, %s PILRenderer anti_aliasing=%d, auto-reset from '
-                      'an HBM pool%s' % (args.workload, args.envs_per_gpu, facts['sprites'], facts['action_space'],
-                                         facts['task'], image, facts['anti_aliasing'],
-                                         ' (BASELINE configs[2])' if (args.workload, args.envs_per_gpu, args.aa) ==
-                                         (WORKLOAD, ENVS_PER_GPU, 5) else ''),
-          'envs_per_gpu': args.envs_per_gpu, 'sprites': facts['sprites'], 'image': facts['image'],
-          'anti_aliasing': facts['anti_aliasing'],
-          'parallelism': 'env-sharded x%d, no data-path collective' % args.gpus,
-      },
-      'roofline': roofline,
-      'env_errors': res['errors'],
-  }
+  out = assemble_line(args, res, elapsed)
   if gather is not None:
     out['obs_allgather'] = gather
   if args.gpus == 1 and not args.no_extra:

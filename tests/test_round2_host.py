@@ -69,3 +69,38 @@ def test_bench_bookkeeping():
   assert bench.algorithmic_bytes(cfg) == 49513
   assert bench.profiled_counters('cluster_s5', 8192, 5, 'not-a-build-id') is None   # stale figures are never reported
   assert bench.usable_cores() >= 1
+
+
+def test_bench_line_carries_the_committed_counters_of_this_build():
+  """bench.assemble_line with the figures of a finished run: for the shipped build (content hash of the kernel
+  sources) the committed PMC passes fill `roofline.traffic` / `roofline.instructions`; the line is valid JSON with
+  the contract's keys; another build id gets nulls."""
+  import argparse
+  import json
+  bench = _bench()
+  build_id = build.source_hash()[:16]
+  for workload, aa, kernel, image, sprites, a_bytes in (('cluster_s5', 5, 'swb_step_kernel<10,1,6>', [64, 64], 5, 12461),
+                                                        ('cluster_s5', 1, 'swb_step_kernel<2,1,8>', [64, 64], 5, 12461),
+                                                        ('embodied_s12', 5, 'swb_step_kernel<20,2,6>', [128, 128], 12, 49513)):
+    args = argparse.Namespace(envs_per_gpu=8192, gpus=1, steps=20, warmup=5, workload=workload, aa=aa)
+    res = dict(elapsed=0.0046, kernel_ms=4.4, launches=20, a_bytes=a_bytes, errors=0,
+               variant=dict(kernel=kernel, build_id=build_id, lds_bytes_per_wave=7200, waves_per_simd=4, nw=10, ncol=1, vs=6),
+               facts=dict(sprites=sprites, image=image, anti_aliasing=aa, action_space='SelectMove', task='Clustering',
+                          max_episode_length=50))
+    line = json.loads(json.dumps(bench.assemble_line(args, res, 0.0046)))
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+      assert key in line, key
+    r = line['roofline']
+    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert r['kernel'] == kernel and r['build_id'] == build_id
+    counters = bench.profiled_counters(workload, 8192, aa, build_id)
+    if counters is None:        # the kernel sources changed after the last PMC passes: stale figures are not reported
+      assert r['traffic'] is None and r['instructions'] is None
+      continue
+    assert counters['kernel'] == kernel
+    assert r['traffic'] == counters['hbm_traffic_bytes_per_launch'] > a_bytes * 8192
+    assert 0.5 < r['instructions']['valu_issue_frac'] < 1.0 and r['instructions']['insts_valu_per_wave'] > 1000
+    res['variant'] = dict(res['variant'], build_id='0000000000000000')
+    stale = bench.assemble_line(args, res, 0.0046)['roofline']
+    assert stale['traffic'] is None and stale['instructions'] is None
