@@ -10,6 +10,7 @@ from spriteworld_amd import _abi
 from spriteworld_amd import lowering
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def golden_cases():

@@ -1,0 +1,99 @@
+"""Builds tests/emu/_build/libswb_emu.so: the sources of spriteworld_amd/csrc compiled for the HOST against the
+emulation shim (tests/emu/shim/hip/hip_runtime.h) -- TEST INFRASTRUCTURE ONLY, see tests/emu/README.md.
+
+The product sources are not edited for this.  Two constructs cannot be compiled for x86 and are rewritten in a
+temporary copy (each rewrite must match, else the build fails):
+  * the four inline-assembly statements (v_med3_i32, three v_mad_i32_i24) -> their C meaning;
+  * the constant-address-space pointer alias (address_space(4), scalar loads on the GPU) -> a plain pointer;
+  * one store in davies_bouldin_wave that relies on the lanes of a wave running in lock step (a cross-lane
+    write-after-read on LDS without a fence) is moved behind a wave_sync().
+"""
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'spriteworld_amd', 'csrc')
+OUT_DIR = os.path.join(HERE, '_build')
+LIB = os.path.join(OUT_DIR, 'libswb_emu.so')
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+SOURCES = ('swb.hip', 'swb_wide.hip', 'swb_kernels.hip.inc', 'swb_pow.hip.inc', 'swb_pow_tables.inc', 'swb_sampler.hip.inc')
+
+
+def _rewrite(text, name):
+  if name != 'swb_kernels.hip.inc':
+    return text
+  n_total = 0
+  text, n = re.subn(r'asm\("v_med3_i32 %0, %1, %2, %3" : "=v"\((\w+)\) : "s"\((\w+)\), "v"\((\w+)\), "v"\((\w+)\)\);',
+                    r'\1 = std::max(std::min(\2, \3), std::min(std::max(\2, \3), \4));   /* emu: median of three */', text)
+  assert n == 1, 'v_med3_i32 statement not found'
+  n_total += n
+  text, n = re.subn(r'asm\("v_mad_i32_i24 %0, %1, %2, %3" : "=v"\(([^)]+)\) : "v"\((\w+)\), "s"\((\w+)\), "v"\(([^)]+)\)\);',
+                    r'\1 = __mul24(\2, \3) + \4;   /* emu: v_mad_i32_i24 */', text)
+  assert n == 3, 'v_mad_i32_i24 statements not found'
+  n_total += n
+  text, n = re.subn(r'using cptr = const T __attribute__\(\(address_space\(4\)\)\)\*;', 'using cptr = const T*;   /* emu */', text)
+  assert n == 1, 'constant address space alias not found'
+  assert 'asm(' not in text.replace('asm("")', ''), 'an inline-assembly statement is left'
+  # Lock-step assumption the fibres cannot honour: davies_bouldin_wave zeroes sc->tmp[l] at the end of a block in which
+  # OTHER lanes still read sc->tmp[] (float64 positions only).  On the GPU the lanes of a wave execute every instruction
+  # together, so all reads of the loop come before the store; here lanes run one after the other between two
+  # rendezvous.  The store is moved behind a wave_sync() (same values; the product source should get the same
+  # treatment next time it is touched -- a cross-lane write-after-read hazard is worth a fence).
+  old = ("    sc->tmp[l] = 0.0;                                               // max_b ratio[a][b], filled below\n"
+         "  }\n  wave_sync();\n")
+  assert text.count(old) == 1, 'davies_bouldin_wave write-after-read site not found'
+  text = text.replace(old, "  }\n  wave_sync();\n  if (l < k) sc->tmp[l] = 0.0;   /* emu: after the fence */\n  wave_sync();\n")
+  return text
+
+
+def source_hash():
+  h = hashlib.sha256()
+  for path in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(ROOT, 'include', 'swb.h'), os.path.join(HERE, 'emu_runtime.cc'),
+                                                          os.path.join(HERE, 'shim', 'hip', 'hip_runtime.h'), os.path.abspath(__file__)]:
+    with open(path, 'rb') as f:
+      h.update(f.read())
+  return h.hexdigest()
+
+
+def build(force=False):
+  stamp = LIB + '.hash'
+  want = source_hash()
+  if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+    return LIB
+  src_dir = os.path.join(OUT_DIR, 'src', 'csrc')
+  shutil.rmtree(os.path.join(OUT_DIR, 'src'), ignore_errors=True)
+  os.makedirs(src_dir)
+  os.makedirs(os.path.join(OUT_DIR, 'include'), exist_ok=True)
+  shutil.copy(os.path.join(ROOT, 'include', 'swb.h'), os.path.join(OUT_DIR, 'include', 'swb.h'))
+  for name in SOURCES:
+    with open(os.path.join(CSRC, name)) as f:
+      text = _rewrite(f.read(), name)
+    with open(os.path.join(src_dir, name), 'w') as f:
+      f.write(text)
+  # the kernels include "../../include/swb.h" relative to csrc/: OUT_DIR/src/csrc -> OUT_DIR/include
+  flags = ['-x', 'c++', '-std=c++17', '-O1', '-g', '-fPIC', '-ffp-contract=off', '-fno-fast-math', '-fno-strict-aliasing',
+           '-I', os.path.join(HERE, 'shim'), '-DSWB_BUILD_ID="emulated"', '-Wno-unused-value', '-Wno-ignored-attributes',
+           '-Wno-unknown-attributes']
+  objs, procs = [], []
+  for unit in ('swb.hip', 'swb_wide.hip'):
+    obj = os.path.join(OUT_DIR, unit + '.o')
+    procs.append(subprocess.Popen([CLANG] + flags + ['-c', '-o', obj, os.path.join(src_dir, unit)]))
+    objs.append(obj)
+  obj = os.path.join(OUT_DIR, 'emu_runtime.o')
+  procs.append(subprocess.Popen([CLANG] + flags + ['-c', '-o', obj, os.path.join(HERE, 'emu_runtime.cc')]))
+  objs.append(obj)
+  for proc in procs:
+    if proc.wait() != 0:
+      raise RuntimeError('emulator build failed')
+  subprocess.check_call([CLANG, '-shared', '-fPIC', '-o', LIB] + objs + ['-lm'])
+  with open(stamp, 'w') as f:
+    f.write(want + '\n')
+  return LIB
+
+
+if __name__ == '__main__':
+  print(build(force=True))

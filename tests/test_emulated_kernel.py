@@ -1,0 +1,161 @@
+"""The kernel SOURCE against the oracle and the reference's recorded outputs, on the CPU.
+
+tests/emu compiles spriteworld_amd/csrc (the C-ABI host side and the fused step kernel, every variant incl. the OV
+builds) for the host against an emulation of the HIP runtime and of the wave-level builtins: work-items are fibres,
+cross-lane operations (ballot, readlane, shuffles, DPP moves, wave barriers) are rendezvous of the 64 lanes that also
+check that all lanes arrive from the same source line.  These tests are what the CPU suite can say about the device
+code where no GPU exists: same inputs, same bar as the `-m gpu` parity tests (state, rewards, step types, discounts
+bit-exact; frames +-0), at sizes the emulator finishes in seconds.
+
+TEST INFRASTRUCTURE: the emulated library is never loaded by the product, proves nothing about timing, register
+allocation or anything else the hipcc build adds -- the `-m gpu` tests run the real thing.  What it does prove is the
+arithmetic and control flow of the kernel source, e.g. before a kernel change is taken to the (scarce) GPU.
+"""
+import numpy as np
+import pytest
+
+from spriteworld_amd import workloads
+from tests import _util
+
+
+def _bits(a):
+  return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _emu(cfg, pool):
+  from tests import _emu_engine
+  return _emu_engine.EmuEngine(cfg, pool)
+
+
+def _emu_torch(cfg, pool):
+  from tests import _emu_engine
+  return _emu_engine.EmuTorchEngine(cfg, pool)
+
+
+def _run(name, n_envs, steps, aa, seed=0):
+  from oracle import oracle
+  cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=3, seed=seed, anti_aliasing=aa)
+  ora, eng = oracle.Engine(cfg, pool), _emu(cfg, pool)
+  rng = np.random.default_rng(seed + 100)
+  for t in range(steps):
+    a = sample(rng)
+    want = ora.step(a)
+    eng.step(a)
+    got = eng.outputs_host()
+    st_o, st_g = ora.state(), eng.state()
+    assert not got['error'].any(), (t, np.flatnonzero(got['error'])[:8])
+    np.testing.assert_array_equal(got['step_type'], want['step_type'], err_msg='step_type t=%d' % t)
+    np.testing.assert_array_equal(_bits(st_g['x']), _bits(st_o['x']), err_msg='x t=%d' % t)
+    np.testing.assert_array_equal(_bits(st_g['y']), _bits(st_o['y']), err_msg='y t=%d' % t)
+    for k in ('step_count', 'reset_next', 'episode', 'pool_entry', 'n_sprites'):
+      np.testing.assert_array_equal(st_g[k], st_o[k], err_msg='%s t=%d' % (k, t))
+    np.testing.assert_array_equal(got['success'], want['success'], err_msg='success t=%d' % t)
+    np.testing.assert_array_equal(got['discount'].view(np.uint32), want['discount'].view(np.uint32))
+    gr, wr = got['reward'], want['reward']
+    assert np.array_equal(np.isnan(gr), np.isnan(wr)), 'reward NaN pattern t=%d' % t
+    ok = ~np.isnan(wr)
+    np.testing.assert_array_equal(_bits(gr[ok]), _bits(wr[ok]), err_msg='reward t=%d' % t)
+    diff = np.abs(got['obs'].astype(np.int16) - want['obs'].astype(np.int16))
+    assert diff.max() == 0, ('frame diff', int(diff.max()), int((diff > 0).sum()), t, np.argwhere(diff > 0)[:5].tolist())
+  eng.close()
+
+
+# the workloads of tests/test_gpu_parity.py (every kernel variant, every task / action space / dtype), a few environments each
+@pytest.mark.parametrize('name,n_envs,steps,aa', [
+    ('goal_s5', 3, 4, 5), ('cluster_s5', 3, 4, 5), ('goal_s5', 3, 3, 1), ('cluster_s5', 3, 3, 1), ('embodied_s12', 2, 3, 5),
+    ('sorting_s4', 3, 4, 5), ('f64_drag', 4, 5, 3), ('f64_cluster', 4, 5, 3), ('cluster6_s12', 3, 4, 2), ('ragged_s16', 8, 4, 5),
+    ('ragged_s16_embodied', 8, 4, 5), ('wide_s4', 2, 3, 5), ('wide_s4', 2, 3, 1), ('tiny_s6', 4, 3, 5), ('tiny_s6', 4, 3, 1),
+    ('goal_s5_f32a', 3, 4, 5), ('cluster_s5_f32a', 3, 4, 5), ('f64_drag_f32a', 3, 4, 3), ('f64_cluster_f32a', 3, 4, 3),
+    ('sorting_s4_f32a', 3, 4, 5)])
+def test_emulated_kernel_equals_oracle(name, n_envs, steps, aa):
+  _run(name, n_envs, steps, aa)
+
+
+@pytest.mark.parametrize('geom,aa', [('96x48', 3), ('48x96', 2), ('256x64', 2), ('160x160', 4), ('128x128', 1),
+                                     ('100x60', 3), ('64x256', 1), ('32x32', 8)])
+def test_emulated_kernel_image_geometries(geom, aa):
+  _run('geom_' + geom, 2, 2, aa)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_emulated_kernel_randomised_configurations(seed):
+  _run('fuzz_%d' % seed, 3, 3, 5, seed=seed)
+
+
+@pytest.mark.parametrize('name,n_envs,aa', [('embodied_s12', 2, 5), ('ragged_s16', 6, 5), ('cluster_s5', 3, 1)])
+def test_emulated_kernel_span_overflow_slots(monkeypatch, name, n_envs, aa):
+  """Rows with more than three visible spans take the HBM overflow path when the LDS lists are switched off."""
+  monkeypatch.setenv('SWB_LDS_SPAN_CAP', '0')
+  _run(name, n_envs, 3, aa)
+
+
+@pytest.mark.parametrize('name', _util.golden_cases())
+def test_emulated_kernel_reproduces_the_reference_fixtures(name):
+  """tests/golden/*.npz (outputs recorded from the unmodified reference): the first 50 steps of every fixture."""
+  cfg, pool, z = _util.load_golden(name)
+  eng = _emu(cfg, pool)
+
+  def step(a):
+    eng.step(a)
+    return eng.outputs_host()
+
+  short = {k: z[k] for k in z.files}
+  short['actions'] = z['actions'][:50]
+  _util.check_against_golden(eng, cfg, short, eng.state, step, 'emu/' + name)
+  eng.close()
+
+
+@pytest.mark.parametrize('name,n_envs,steps,aa', [('goal_s5', 6, 5, 5), ('cluster_s5', 6, 4, 1), ('embodied_s12', 3, 3, 5),
+                                                   ('geom_256x64', 3, 3, 2), ('geom_32x32', 3, 3, 8)])
+def test_emulated_ov_kernels_sprite_setters(name, n_envs, steps, aa):
+  """The scenarios of tests/test_gpu_setters.py on the emulated library: swb_set_sprite_attr's host arithmetic, the
+  override arrays and the OV builds of the step kernel against the oracle's setters."""
+  from tests import _setter_cases
+  _setter_cases.run_parity(_emu_torch, name, n_envs, steps, aa)
+
+
+def test_emulated_setters_factors_and_reset():
+  from tests import _emu_engine, _setter_cases
+  _setter_cases.factors_and_reset_case(_emu_torch, _emu_engine.EmuError)
+
+
+def test_emulated_live_sprite_handles(monkeypatch):
+  """environment.BatchedEnvironment + sprite.LiveSprite on the emulated library, checked against matplotlib."""
+  from spriteworld_amd import environment
+  from tests import _emu_engine, _setter_cases
+  monkeypatch.setattr(environment._engine, 'Engine', _emu_engine.EmuTorchEngine)
+  _setter_cases.live_sprite_case()
+
+
+def test_emulator_refuses_cross_lane_operations_under_divergence():
+  """The rendezvous checks the call site: the build carries a self-test kernel whose lanes reach two different
+  ballots; it must be caught (subprocess: the emulator aborts)."""
+  import subprocess
+  import sys
+  code = ('import ctypes, sys; sys.path.insert(0, %r); from tests.emu import build_emu; '
+          'l = ctypes.CDLL(build_emu.build()); l.emu_selftest_divergent_ballot()' % _util.ROOT)
+  p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+  assert p.returncode != 0 and 'divergent control flow' in p.stderr, p.stderr[-500:]
+
+
+# ---- the device-side reset sampler (swb_sampler.hip.inc, one work-item per pool entry) on the emulated library:
+# the `-m gpu` tests of tests/test_device_sampler.py, called with the engine interface backed by the emulator
+def _patch_engine(monkeypatch):
+  from spriteworld_amd import environment
+  from tests import _emu_engine
+  monkeypatch.setattr(environment._engine, 'Engine', _emu_engine.EmuTorchEngine)
+
+
+@pytest.mark.parametrize('case', ['cobra_like', 'embodied_like', 'holdouts', 'hsv_mixed', 'mixed_types', 'sorting_like'])
+def test_emulated_sampler_kernel_equals_the_python_model(monkeypatch, case):
+  from tests import test_device_sampler as T
+  assert sorted(T.CASES) == ['cobra_like', 'embodied_like', 'holdouts', 'hsv_mixed', 'mixed_types', 'sorting_like']
+  _patch_engine(monkeypatch)
+  T.test_device_pool_matches_the_model_bit_for_bit(case)
+
+
+def test_emulated_sampler_shards_and_refresh(monkeypatch):
+  from tests import test_device_sampler as T
+  _patch_engine(monkeypatch)
+  T.test_shards_draw_the_episodes_of_the_whole_job()
+  T.test_refresh_pool_redraws_everything_but_the_live_entries()

@@ -3,7 +3,8 @@
 Each case cites the reference test it restates (file:line under /root/reference/tests).  The
 reference tests cannot run here as written (absl / mock / dm_env are absent),
 so the vectors are fed through the batched boundary instead: sprites -> pool, task/action space ->
-SwbConfig, then `step()` on the CPU oracle (`kind='oracle'`) or the HIP engine (`kind='hip'`, GPU).
+SwbConfig, then `step()` on the CPU oracle (`kind='oracle'`), the HIP engine (`kind='hip'`, GPU) or the kernel source
+run by the host emulator (`kind='emu'`, tests/emu).
 """
 import numpy as np
 import pytest
@@ -12,7 +13,9 @@ from spriteworld_amd import action_spaces, lowering, renderers, tasks
 from spriteworld_amd import factor_distributions as distribs
 from spriteworld_amd.sprite import Sprite
 
-KINDS = ['oracle', pytest.param('hip', marks=pytest.mark.gpu)]
+# 'emu': the kernel source executed lane by lane on the host (tests/emu, test infrastructure) -- what the CPU suite can
+# say about the device code where no GPU exists
+KINDS = ['oracle', 'emu', pytest.param('hip', marks=pytest.mark.gpu)]
 
 
 class Harness(object):
@@ -33,6 +36,9 @@ class Harness(object):
     if kind == 'oracle':
       from oracle import oracle
       self.eng = oracle.Engine(self.cfg, self.pool)
+    elif kind == 'emu':
+      from tests import _emu_engine
+      self.eng = _emu_engine.EmuEngine(self.cfg, self.pool)
     else:
       from spriteworld_amd import engine
       self.eng = engine.Engine(self.cfg, self.pool)
