@@ -16,8 +16,10 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-CSRC = os.path.join(ROOT, 'spriteworld_amd', 'csrc')
-OUT_DIR = os.path.join(HERE, '_build')
+# SWB_EMU_CSRC: emulate another copy of the kernel sources (tools/try_patch.py: a patched copy on its way to the GPU)
+CSRC = os.path.abspath(os.environ.get('SWB_EMU_CSRC') or os.path.join(ROOT, 'spriteworld_amd', 'csrc'))
+OUT_DIR = os.path.join(HERE, '_build') if not os.environ.get('SWB_EMU_CSRC') else \
+    os.path.join(HERE, '_build', 'alt_' + hashlib.sha256(CSRC.encode()).hexdigest()[:8])
 LIB = os.path.join(OUT_DIR, 'libswb_emu.so')
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 SOURCES = ('swb.hip', 'swb_wide.hip', 'swb_kernels.hip.inc', 'swb_pow.hip.inc', 'swb_pow_tables.inc', 'swb_sampler.hip.inc')
@@ -45,8 +47,10 @@ def _rewrite(text, name):
   # treatment next time it is touched -- a cross-lane write-after-read hazard is worth a fence).
   old = ("    sc->tmp[l] = 0.0;                                               // max_b ratio[a][b], filled below\n"
          "  }\n  wave_sync();\n")
-  assert text.count(old) == 1, 'davies_bouldin_wave write-after-read site not found'
-  text = text.replace(old, "  }\n  wave_sync();\n  if (l < k) sc->tmp[l] = 0.0;   /* emu: after the fence */\n  wave_sync();\n")
+  if text.count(old) == 1:
+    text = text.replace(old, "  }\n  wave_sync();\n  if (l < k) sc->tmp[l] = 0.0;   /* emu: after the fence */\n  wave_sync();\n")
+  else:       # sources that already carry the fence (tools/next_round/a_fence_davies_bouldin_war.patch)
+    assert 'if (l < k) sc->tmp[l] = 0.0;' in text, 'davies_bouldin_wave write-after-read site not found'
   return text
 
 
@@ -67,6 +71,7 @@ def build(force=False):
   src_dir = os.path.join(OUT_DIR, 'src', 'csrc')
   shutil.rmtree(os.path.join(OUT_DIR, 'src'), ignore_errors=True)
   os.makedirs(src_dir)
+  os.makedirs(OUT_DIR, exist_ok=True)
   os.makedirs(os.path.join(OUT_DIR, 'include'), exist_ok=True)
   shutil.copy(os.path.join(ROOT, 'include', 'swb.h'), os.path.join(OUT_DIR, 'include', 'swb.h'))
   for name in SOURCES:

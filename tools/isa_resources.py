@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """ISA resource table of every swb_step_kernel variant of the shipped sources: compiles both translation units with the
 flags of spriteworld_amd/build.py plus -save-temps (in a temporary directory) and reads the kernel descriptors' metadata.
-usage: python tools/isa_resources.py > table.md"""
+usage: python tools/isa_resources.py [CSRC_DIR] > table.md"""
 import os
 import re
 import subprocess
@@ -32,10 +32,11 @@ def kernels_of(asm):
 
 def main():
   rows = []
+  csrc = os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else build.CSRC        # another copy of the sources (tools/try_patch.py)
   with tempfile.TemporaryDirectory() as tmp:
     for unit, extra in build.UNITS:
       cmd = ['hipcc'] + build.COMMON + extra + ['-DSWB_BUILD_ID="isa"', '-save-temps', '-c', '-o', os.path.join(tmp, unit + '.o'),
-                                               os.path.join(build.CSRC, unit)]
+                                               os.path.join(csrc, unit)]
       subprocess.check_call(cmd, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
       asm = open(os.path.join(tmp, unit.replace('.hip', '') + '-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
       for key, r in kernels_of(asm).items():
