@@ -20,6 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.abspath(os.environ.get('SWB_EMU_CSRC') or os.path.join(ROOT, 'spriteworld_amd', 'csrc'))
 OUT_DIR = os.path.join(HERE, '_build') if not os.environ.get('SWB_EMU_CSRC') else \
     os.path.join(HERE, '_build', 'alt_' + hashlib.sha256(CSRC.encode()).hexdigest()[:8])
+if os.environ.get('SWB_EMU_STATS'):
+  OUT_DIR = os.path.join(OUT_DIR, 'stats')
 LIB = os.path.join(OUT_DIR, 'libswb_emu.so')
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 SOURCES = ('swb.hip', 'swb_wide.hip', 'swb_kernels.hip.inc', 'swb_pow.hip.inc', 'swb_pow_tables.inc', 'swb_sampler.hip.inc')
@@ -51,6 +53,41 @@ def _rewrite(text, name):
     text = text.replace(old, "  }\n  wave_sync();\n  if (l < k) sc->tmp[l] = 0.0;   /* emu: after the fence */\n  wave_sync();\n")
   else:       # sources that already carry the fence (tools/next_round/a_fence_davies_bouldin_war.patch)
     assert 'if (l < k) sc->tmp[l] = 0.0;' in text, 'davies_bouldin_wave write-after-read site not found'
+  if os.environ.get('SWB_EMU_STATS'):
+    text = _instrument(text)
+  return text
+
+
+# SWB_EMU_STATS=1: event counters at a few anchor points of the kernel source (counted by lane 0 of each wave), read back
+# through emu_stats() -- exact dynamic figures for the cost model in DESIGN.md (tools/emu_stats.py).
+_COUNTERS = ('p3_row_runs', 'p3_rows_in_runs', 'p3_spans', 'p3_nonempty_rows', 'p3_completed_rows', 'p2_batches',
+             'p2_sprite_passes', 'p2_edge_iterations', 'p2_transition_steps')
+
+
+def _instrument(text):
+  def hook(counter, amount='1'):
+    return ' emu_count(%d, %s);' % (_COUNTERS.index(counter), amount)
+
+  def after(anchor, code, count=1):
+    nonlocal text
+    assert text.count(anchor) == count, (anchor, text.count(anchor))
+    text = text.replace(anchor, anchor + code)
+
+  text = text.replace('#define SWB_WAVE 64', '#define SWB_WAVE 64\nextern "C" void emu_count(int counter, long amount);', 1)
+  after('          const int r = __builtin_ctzll(mask);', hook('p3_row_runs'))
+  after('            const int e = __builtin_ctzll(ends);', hook('p3_rows_in_runs', '__builtin_popcountll(mask & (~0ull >> (63 - e)))'))
+  after('          first_span(sp0, h);', hook('p3_spans'))
+  after('            add_span((uint32_t)__builtin_amdgcn_readlane((int)rs.s1, r), h);', hook('p3_spans'))
+  after('              add_span((uint32_t)__builtin_amdgcn_readlane((int)rs.s2, r), h);', hook('p3_spans') + hook('p3_spans', 'ns - 3'))
+  after('      unsigned long long todo = (p.bg == 0u) ? __ballot(rs.cnt != 0u) : ~0ull;', hook('p3_nonempty_rows', '__builtin_popcountll(todo & (rows < 64 ? (1ull << rows) - 1ull : ~0ull))'))
+  after('    auto complete_row = [&]() __attribute__((always_inline)) {', hook('p3_completed_rows'))
+  after('    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)sp_a, s);', hook('p2_sprite_passes'))
+  after('  rs.cnt = 0; rs.s0 = rs.s1 = rs.s2 = 0u;', hook('p2_batches'))
+  after('        for (int e = 0; e < ne; ++e) {', hook('p2_edge_iterations'))
+  after('        for (int j = 0; j < bound; j += (1 << lg)) {', hook('p2_edge_iterations'))
+  anchor = '        auto take = [&]() __attribute__((always_inline)) {'
+  assert text.count(anchor) == 1, anchor
+  text = text.replace(anchor, anchor + hook('p2_transition_steps') + ' ')
   return text
 
 

@@ -205,3 +205,14 @@ extern "C" void emu_selftest_divergent_ballot() {
     (void)m;
   }, dim3(1), dim3(64), 64);
 }
+
+// Event counters of an instrumented build (SWB_EMU_STATS=1, tests/emu/build_emu.py): counted by lane 0 of a wave.
+static long g_emu_counters[32];
+extern "C" void emu_count(int counter, long amount) {
+  if (emu::self().lane == 0 && counter >= 0 && counter < 32) g_emu_counters[counter] += amount;
+}
+extern "C" long emu_stats(int counter, int reset) {
+  const long v = (counter >= 0 && counter < 32) ? g_emu_counters[counter] : 0;
+  if (reset) memset(g_emu_counters, 0, sizeof(g_emu_counters));
+  return v;
+}
