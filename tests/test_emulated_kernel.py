@@ -159,3 +159,54 @@ def test_emulated_sampler_shards_and_refresh(monkeypatch):
   _patch_engine(monkeypatch)
   T.test_shards_draw_the_episodes_of_the_whole_job()
   T.test_refresh_pool_redraws_everything_but_the_live_entries()
+
+
+@pytest.mark.skipif(not __import__('oracle.ref_harness', fromlist=['x']).reference_available(), reason='reference tree not present')
+def test_emulated_factors_kernel_equals_reference_sprite_factors():
+  """renderers/handcrafted.py:29-82 SpriteFactors of the UNMODIFIED reference on a running environment (incl. sprites
+  modified through the setters, sprite.py:152-175) against swb_factors of the emulated library, every step."""
+  import copy
+  from oracle import ref_harness
+  ref_harness.load_reference()
+  from spriteworld import action_spaces, environment, renderers, sprite, tasks
+  from spriteworld_amd import _abi, lowering, shapes
+  from spriteworld_amd import sprite as sprite_lib
+  rng = np.random.RandomState(8)
+  names = list(shapes.SHAPES.keys())
+
+  def gen():
+    return [sprite.Sprite(x=float(rng.uniform(0.2, 0.8)), y=float(rng.uniform(0.2, 0.8)), shape=str(rng.choice(names)),
+                          angle=float(rng.choice([0, 40, 200])), scale=float(rng.choice([0.1, 0.2])),
+                          c0=int(rng.randint(0, 256)), c1=int(rng.randint(0, 256)), c2=int(rng.randint(0, 256)),
+                          x_vel=float(rng.uniform(-0.01, 0.01)), y_vel=float(rng.uniform(-0.01, 0.01)))
+            for _ in range(int(rng.randint(1, 4)))]
+
+  episodes = [gen() for _ in range(5)]
+  task = tasks.FindGoalPosition(goal_position=(0.5, 0.5), terminate_distance=0.05)
+  aspace = action_spaces.SelectMove(scale=0.2)
+  rends = {'image': renderers.PILRenderer(image_size=(32, 32), anti_aliasing=2), 'factors': renderers.SpriteFactors()}
+  cfg = lowering.lower_config(task, aspace, {'image': rends['image']}, True, 9, 1, 3,
+                              pos_is_f32=(lowering.position_dtype(episodes) == np.float32))
+  pool = lowering.lower_episodes(episodes, task, {'image': rends['image']}, max_sprites=3).assign_round_robin(1)
+  eng = _emu(cfg, pool)
+  it = (copy.deepcopy(e) for e in [episodes[0]] + episodes * 20)
+  env = environment.Environment(task=task, action_space=aspace, renderers=rends, init_sprites=lambda: next(it),
+                                keep_in_frame=True, max_episode_length=9)
+  arng = np.random.RandomState(3)
+  for t in range(40):
+    if t % 4 == 2 and env._sprites and not env._reset_next_step:
+      k = int(arng.randint(0, len(env._sprites)))
+      attr, value = [('angle', 77.0), ('scale', 0.33), ('shape', 'star_5')][(t // 4) % 3]
+      setattr(env._sprites[k], attr, value)
+      eng.set_sprite_attr(0, k, {'shape': _abi.ATTR_SHAPE, 'angle': _abi.ATTR_ANGLE, 'scale': _abi.ATTR_SCALE}[attr],
+                          shapes.shape_index(value) if attr == 'shape' else value)
+    a = arng.uniform(0, 1, 4)
+    ts = env.step(a)
+    eng.step(a[None])
+    got = eng.factors()[0]
+    want = ts.observation['factors']
+    assert len(want) == eng.state()['n_sprites'][0]
+    for s, row in enumerate(want):
+      assert [row[f] for f in sprite_lib.FACTOR_NAMES] == got[s].tolist(), (t, s)
+    assert not got[len(want):].any()
+    assert np.array_equal(ts.observation['image'], eng.outputs_host()['obs'][0]), t
