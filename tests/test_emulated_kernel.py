@@ -210,3 +210,58 @@ def test_emulated_factors_kernel_equals_reference_sprite_factors():
       assert [row[f] for f in sprite_lib.FACTOR_NAMES] == got[s].tolist(), (t, s)
     assert not got[len(want):].any()
     assert np.array_equal(ts.observation['image'], eng.outputs_host()['obs'][0]), t
+
+
+def _reference_configs():
+  from tests import test_oracle_vs_reference as R
+  return R.CONFIGS
+
+
+@pytest.mark.skipif(not __import__('oracle.ref_harness', fromlist=['x']).reference_available(), reason='reference tree not present')
+@pytest.mark.parametrize('module,mode', _reference_configs())
+def test_emulated_kernel_equals_the_unmodified_reference(module, mode):
+  """Every shipped config in both modes (tests/configs/configs_test.py:33-58 runs the same grid): the UNMODIFIED reference
+  `Environment` and the kernel source (emulated) stepped side by side in one process, no oracle in between -- step
+  types, rewards, positions bit-exact, frames +-0, across resets."""
+  import importlib
+  from oracle import ref_harness
+  ref_harness.load_reference()
+  from spriteworld import environment
+  from spriteworld import renderers as ref_renderers
+  from spriteworld_amd import lowering
+  from tests import test_oracle_vs_reference as R
+  seed, n_eps, n_steps = 33, 12, 100
+  np.random.seed(seed)
+  config = importlib.import_module(module).get_config(mode)
+  episodes = [config['init_sprites']() for _ in range(n_eps)]
+  task, aspace, rends = config['task'], config['action_space'], config['renderers']
+  S = max(len(e) for e in episodes)
+  cfg = lowering.lower_config(task, aspace, rends, True, config['max_episode_length'], 1, S,
+                              pos_is_f32=(lowering.position_dtype(episodes) == np.float32))
+  pool = lowering.lower_episodes(episodes, task, rends, max_sprites=S).assign_round_robin(1)
+  eng = _emu(cfg, pool)
+  it = R._fresh_episodes(episodes)
+  config = dict(config, init_sprites=lambda: next(it))
+  config['renderers'] = dict(rends, success=ref_renderers.Success())
+  env = environment.Environment(**config)
+  rng = np.random.RandomState(seed + 1)
+  for t in range(n_steps):
+    if cfg.action_space == 2:
+      a = np.array([rng.randint(0, 2), rng.randint(0, 4)])
+      ts = env.step([int(a[0]), int(a[1])])
+    else:
+      a = rng.uniform(0, 1, 4)
+      ts = env.step(a)
+    eng.step(a[None])
+    out = eng.outputs_host()
+    assert not out['error'][0], t
+    assert int(ts.step_type) == int(out['step_type'][0]), t
+    r = np.nan if ts.reward is None else float(ts.reward)
+    assert (np.isnan(r) and np.isnan(out['reward'][0])) or _bits(r) == _bits(out['reward'][0]), (t, r)
+    assert bool(ts.observation['success']) == bool(out['success'][0]), t
+    assert np.array_equal(ts.observation['image'], out['obs'][0]), t
+    st = eng.state()
+    pos = np.array([s.position for s in env._sprites], dtype=np.float64).reshape(-1, 2)
+    n = st['n_sprites'][0]
+    assert n == len(pos) and np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
+  eng.close()

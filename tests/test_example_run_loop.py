@@ -7,9 +7,11 @@ config dict (its task / action-space / renderer / generator objects) goes unchan
 `spriteworld_amd.environment.Environment`, is lowered and stepped through the engine interface; the per-episode
 log lines (success, mean reward) and every time step must be identical.
 
-Where this container has no GPU the engine behind the interface is tests/_fake_engine.py (the CPU oracle with the
-engine's method surface); the HIP engine is compared with the same oracle bit for bit by the `-m gpu` tests.
-/root/reference does not exist on the GPU box, so the two halves cannot meet in one process anywhere.
+This container has no GPU, so the engine behind the interface is (a) tests/_fake_engine.py, the CPU oracle with the
+engine's method surface, and (b) tests/_emu_engine.py, the library's own sources -- C-ABI host side and the fused step
+kernel -- compiled for the host and executed lane by lane (tests/emu).  The hipcc build of the same sources is compared
+with the oracle bit for bit by the `-m gpu` tests; /root/reference does not exist on the GPU box, so reference and GPU
+cannot meet in one process anywhere.
 """
 import copy
 import importlib
@@ -94,12 +96,18 @@ def _run_main(monkeypatch, run_loop, episodes, use_dropin, steps):
   return handler.lines
 
 
-def test_example_run_loop_main_drives_the_dropin(monkeypatch):
+@pytest.mark.parametrize('backend', ['oracle', 'emulated_kernel'])
+def test_example_run_loop_main_drives_the_dropin(monkeypatch, backend):
   ref_harness.load_reference()
   from spriteworld_amd import environment as amd_environment
-  from tests import _fake_engine
   run_loop = importlib.import_module('example_run_loop')
-  monkeypatch.setattr(amd_environment._engine, 'Engine', _fake_engine.FakeEngine)
+  if backend == 'oracle':
+    from tests import _fake_engine
+    engine_class = _fake_engine.FakeEngine
+  else:       # the kernel source itself, run lane by lane on the host (tests/emu)
+    from tests import _emu_engine
+    engine_class = _emu_engine.EmuTorchEngine
+  monkeypatch.setattr(amd_environment._engine, 'Engine', engine_class)
   np.random.seed(5)
   episodes = [importlib.import_module(CONFIG).get_config('train')['init_sprites']() for _ in range(N_EPISODES + 2)]
   ref_steps, our_steps = [], []
