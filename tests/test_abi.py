@@ -79,3 +79,31 @@ def test_product_never_imports_the_oracle():
       elif f.endswith(('.hip', '.inc', '.h')):
         for line in open(path):
           assert not (line.lstrip().startswith('#include') and 'oracle' in line), (f, line)
+
+
+def test_product_package_never_reaches_for_the_checkers():
+  """The oracle (oracle/) and the host emulation of the kernels (tests/emu) are test infrastructure: nothing under
+  spriteworld_amd/ imports, loads or names them (comments in docstrings aside), so no product path can route through
+  a CPU implementation -- without libswb.so and a GPU the engine raises (test_engine_fails_loudly_without_gpu)."""
+  import ast
+  pkg = os.path.join(ROOT, 'spriteworld_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for name in files:
+      if not name.endswith('.py'):
+        continue
+      path = os.path.join(dirpath, name)
+      tree = ast.parse(open(path).read())
+      for node in ast.walk(tree):
+        mods = []
+        if isinstance(node, ast.Import):
+          mods = [a.name for a in node.names]
+        elif isinstance(node, ast.ImportFrom):
+          mods = [node.module or '']
+        for m in mods:
+          assert not (m == 'oracle' or m.startswith('oracle.') or m == 'tests' or m.startswith('tests.')), (path, m)
+        if isinstance(node, ast.Constant) and isinstance(node.value, str) and node is not getattr(tree.body[0], 'value', None):
+          assert 'libswb_emu' not in node.value and 'libsw_oracle' not in node.value, (path, node.value[:60])
+  for name in os.listdir(os.path.join(pkg, 'csrc')):
+    if name.endswith(('.hip', '.inc')):
+      text = open(os.path.join(pkg, 'csrc', name)).read()
+      assert '#include "../../oracle' not in text and 'tests/emu/' not in text.replace('tests/emu found it', ''), name
