@@ -151,7 +151,10 @@ void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, size_t l
   g_body = &body;
   g_threads = threads;
   for (unsigned b = 0; b < grid.x; ++b) {
-    memset(smem, 0xA5, lds_bytes ? lds_bytes : 64);      // LDS is not zero-initialised on the device either
+    // LDS is not initialised on the device: a garbage pattern (SWB_EMU_LDS_FILL overrides the byte, to check that no
+    // result depends on what a previous workgroup left there)
+    static const int fill = getenv("SWB_EMU_LDS_FILL") ? (int)strtol(getenv("SWB_EMU_LDS_FILL"), nullptr, 0) : 0xA5;
+    memset(smem, fill, lds_bytes ? lds_bytes : 64);
     for (int t = 0; t < threads; ++t) {
       fibre& f = g_fibres[t];
       prepare(f);
@@ -163,7 +166,11 @@ void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, size_t l
     for (int w = 0; w < (threads + 63) / 64; ++w) { g_waves[w] = wave_state(); }
     for (;;) {
       bool any = false, progressed = false;
-      for (int t = 0; t < threads; ++t) {
+      for (int t0 = 0; t0 < threads; ++t0) {
+        // SWB_EMU_LANE_ORDER=reverse: lanes take their turns in descending order -- results must not depend on the order
+        // in which lanes run between two rendezvous (a cross-lane LDS hazard without a fence would show)
+        static const bool reverse = getenv("SWB_EMU_LANE_ORDER") && !strcmp(getenv("SWB_EMU_LANE_ORDER"), "reverse");
+        const int t = reverse ? threads - 1 - t0 : t0;
         fibre& f = g_fibres[t];
         if (f.done) continue;
         any = true;

@@ -265,3 +265,17 @@ def test_emulated_kernel_equals_the_unmodified_reference(module, mode):
     n = st['n_sprites'][0]
     assert n == len(pos) and np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
   eng.close()
+
+
+def test_emulated_results_do_not_depend_on_lane_order_or_lds_garbage():
+  """The same parity tests with the lanes taking their turns in DESCENDING order between rendezvous and another garbage
+  byte in the uninitialised LDS (both are read once per process: a subprocess).  A cross-lane hazard on LDS without a
+  fence, or a read of LDS nothing wrote, would change a result."""
+  import os
+  import subprocess
+  import sys
+  env = dict(os.environ, SWB_EMU_LANE_ORDER='reverse', SWB_EMU_LDS_FILL='0x00')
+  p = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider', '-k',
+                      'equals_oracle and (cluster_s5 or embodied or f64_cluster or ragged_s16 or tiny or sorting) or setters and goal_s5'],
+                     cwd=_util.ROOT, env=env, capture_output=True, text=True)
+  assert p.returncode == 0 and ' passed' in p.stdout, p.stdout[-1500:]
