@@ -279,3 +279,25 @@ def test_emulated_results_do_not_depend_on_lane_order_or_lds_garbage():
                       'equals_oracle and (cluster_s5 or embodied or f64_cluster or ragged_s16 or tiny or sorting) or setters and goal_s5'],
                      cwd=_util.ROOT, env=env, capture_output=True, text=True)
   assert p.returncode == 0 and ' passed' in p.stdout, p.stdout[-1500:]
+
+
+# ---- host-API tests written for the GPU (tests/test_env_spec_conformance.py, test_gym_wrapper.py, test_host_api.py),
+# run here with the engine interface backed by the emulated library: the dm_env / gym surface over the kernel source
+def test_emulated_environment_conforms_to_its_specs(monkeypatch):
+  """tests/environment_test.py:30-51 (dm_env EnvironmentTestMixin), as re-expressed for the N = 1 Environment."""
+  from tests import test_env_spec_conformance as T
+  _patch_engine(monkeypatch)
+  for make in (T._reference_test_env, T._rendered_env):
+    T.test_reset_and_step_protocol_on_fresh_environments(make)
+    T.test_longer_action_sequence_conforms_to_the_specs(make)
+  T.test_specs_are_specs()
+
+
+def test_emulated_gym_wrapper_and_single_environment(monkeypatch):
+  from tests import test_gym_wrapper as G
+  from tests import test_host_api as H
+  _patch_engine(monkeypatch)
+  for embodied in (False, True):
+    G.test_reference_gym_wrapper_episode_pattern(embodied)
+  H.test_single_environment_follows_example_run_loop()
+  H.test_sprite_factors_observation_and_action_noise()
