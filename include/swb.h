@@ -332,9 +332,15 @@ int swb_sprite_path_op(int32_t attr, double a, double b, int32_t n, const double
  * run by what actually ran.  swb_build_id(): content hash of the sources and flags the library was
  * built from (spriteworld_amd/build.py), "unknown" for a hand build. */
 typedef struct swb_variant_info {
-  int32_t nw, ncol, vs;
-  int32_t lds_bytes_per_wave;
-  int32_t waves_per_simd;     /* register budget the kernel was compiled for */
+  int32_t nw;                 /* cover kernel: 32-pixel words per canvas row it is built for */
+  int32_t ncol;               /* output columns per lane of the second kernel (always 1: wider images are column groups) */
+  int32_t vs;                 /* resample kernel: output rows in flight (0: anti_aliasing = 1, the fill kernel) */
+  int32_t lds_bytes_per_wave; /* cover kernel, = per environment */
+  int32_t waves_per_simd;     /* register budget the cover kernel was compiled for */
+  int32_t resample_waves_per_simd; /* ... the resample / fill kernel */
+  int32_t n_bands;            /* bands of output rows: waves of the second kernel per (environment, column group) */
+  int32_t n_column_groups;    /* groups of 64 output columns */
+  int32_t run_cap;            /* capacity of a run list (8-byte units per environment and column group) */
 } swb_variant_info;
 int swb_variant(swb_handle h, swb_variant_info* out);
 const char* swb_build_id(void);
@@ -343,6 +349,9 @@ const char* swb_build_id(void);
  * while enabled; swb_step_time_ms returns (total ms, launches) since enable. */
 int swb_timing_enable(swb_handle h, int32_t enable);
 int swb_step_time_ms(swb_handle h, double* total_ms, int64_t* launches);
+/* The same interval split at the event between the two kernels of a step: cover (state, geometry,
+ * coverage -> run lists) and resample / fill (run lists -> frames). */
+int swb_kernel_times_ms(swb_handle h, double* cover_ms, double* resample_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,8 @@
 // swb.hip -- C-ABI host side of the batched Spriteworld engine (see include/swb.h).
 //
-// Owns the device copies of the constant tables, the reset pool and the live
-// structure-of-arrays state; launches the fused step kernel (swb_kernels.hip.inc).
+// Owns the device copies of the constant tables, the reset pool, the live structure-of-arrays
+// state and the run lists handed from the cover kernel to the resample / fill kernel; launches the
+// two kernels of a step (swb_kernels.hip.inc).
 // Built only for gfx950:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 #include <hip/hip_runtime.h>
 
@@ -18,18 +19,9 @@
 #include "swb_pow.hip.inc"
 #include "swb_sampler.hip.inc"
 
-// the kernels of images wider than 64 columns are instantiated in swb_wide.hip (other scheduler flags)
-extern template __global__ void swb_step_kernel<4, 2, 8>(const swb_params);
-extern template __global__ void swb_step_kernel<10, 2, 8>(const swb_params);
-extern template __global__ void swb_step_kernel<20, 2, 6>(const swb_params);
-extern template __global__ void swb_step_kernel<20, 2, 8>(const swb_params);
-extern template __global__ void swb_step_kernel<20, 4, 8>(const swb_params);
-extern template __global__ void swb_step_kernel<4, 2, 8, true>(const swb_params);
-extern template __global__ void swb_step_kernel<10, 2, 8, true>(const swb_params);
-extern template __global__ void swb_step_kernel<20, 2, 6, true>(const swb_params);
-extern template __global__ void swb_step_kernel<20, 2, 8, true>(const swb_params);
-extern template __global__ void swb_step_kernel<20, 4, 8, true>(const swb_params);
-
+// the cover kernels of canvases wider than 320 px are instantiated in swb_wide.hip (other scheduler flags)
+extern template __global__ void swb_cover_kernel<20, false>(const swb_params);
+extern template __global__ void swb_cover_kernel<20, true>(const swb_params);
 
 namespace {
 
@@ -68,9 +60,13 @@ struct swb_engine {
   int device = 0;
   swb_params p;        // device pointers + config, passed by value to the kernel
   bool have_shapes = false, have_h = false, have_v = false, have_pool = false;
-  int nw = 0, ncol = 0, vslots = SWB_VSLOTS;
+  int vslots = SWB_VSLOTS;
+  int nbands = 1;                    // bands of output rows per (environment, column group) in the resample / fill kernel
+  bool tables_dirty = true;          // band / break / column-group tables follow the resampling tables and nbands
+  std::vector<int32_t> v_ymin_host, v_end_host, h_xmin_host, h_cnt_host;
   std::vector<int> shape_nverts;     // vertices per uploaded shape
   int ovf_lds_bytes = 0;             // LDS footprint the overflow slots were sized with
+  void (*ovf_fn)(const swb_params) = nullptr;   // ... and the cover kernel (plain or override build)
   size_t lds_block = 0;
   // owned device buffers
   double* d_shape_verts = nullptr;
@@ -94,6 +90,16 @@ struct swb_engine {
   uint8_t* d_reset_next = nullptr;
   uint32_t *d_ovf = nullptr, *d_ovf_bitmap = nullptr;
   int ovf_slots = 0;
+  // A step may be issued as `groups` groups of environments: the cover kernels one after the other on the caller's
+  // stream, each group's resample kernel on an internal stream as soon as its cover kernel is done -- so that the
+  // latency-bound cover kernel of group g + 1 shares the machine with the ALU-bound resample kernel of group g.
+  int groups = 1, group_first = 0;   // group_first: environments in the first group (0: equal groups)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_cover[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;
+  // hand-off cover -> resample
+  uint32_t *d_runs = nullptr, *d_rhdr = nullptr;
+  int32_t *d_band_y0 = nullptr, *d_band_first = nullptr, *d_band_lo = nullptr, *d_cg_lo = nullptr, *d_cg_hi = nullptr;
+  uint32_t* d_v_break = nullptr;
   // live sprite overrides (swb_set_sprite_attr), allocated at the first call
   uint8_t* d_ov_flag = nullptr;
   int32_t* d_ov_shape = nullptr;
@@ -101,8 +107,9 @@ struct swb_engine {
   int8_t* d_ov_label = nullptr;
   // timing
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  double timed_ms = 0.0;
+  struct step_events { hipEvent_t e0, e1, e2; };     // before cover, between the kernels, after resample / fill
+  std::vector<step_events> events;
+  double timed_ms = 0.0, timed_cover_ms = 0.0;
   int64_t timed_launches = 0;
 };
 
@@ -110,52 +117,52 @@ namespace {
 
 typedef void (*kernel_fn)(const swb_params);
 
-struct variant { int nw, ncol, vs; kernel_fn fn, fn_ov; size_t lds_fixed, outrow_bytes; };
+// cover kernel by canvas width (NW 32-pixel words per canvas row); resample kernel by the output rows a canvas
+// row can feed at once (VS)
+struct variant { int nw; kernel_fn fn, fn_ov; size_t lds_fixed, outrow_bytes; };
 
-template <int NW, int NCOL, int VS>
+template <int NW>
 variant make_variant() {
-  // wave_lds<NW> + the output-row staging (3 bytes per pixel; never less than build_all_edges' 98 dwords of scratch)
-  const size_t outrow = std::max<size_t>(392, (size_t)NCOL * 64 * 3);
-  return {NW, NCOL, VS, swb_step_kernel<NW, NCOL, VS>, swb_step_kernel<NW, NCOL, VS, true>,
-          (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
+  const size_t outrow = 392;          // wave_lds::outrow is build_all_edges' scratch (98 dwords)
+  return {NW, swb_cover_kernel<NW>, swb_cover_kernel<NW, true>, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
 }
 
-// canvas widths up to 32*NW pixels, image widths up to 64*NCOL pixels, up to VS output rows in
-// flight in the vertical pass (first match wins)
-const variant kVariants[] = {
-    make_variant<2, 1, 8>(),  make_variant<4, 1, 8>(),  make_variant<4, 2, 8>(),  make_variant<5, 1, 8>(),
-    make_variant<10, 1, 6>(), make_variant<10, 1, 8>(), make_variant<10, 2, 8>(),
-    make_variant<20, 2, 6>(), make_variant<20, 2, 8>(), make_variant<20, 4, 8>(),
-};
+const variant kVariants[] = {make_variant<2>(), make_variant<4>(), make_variant<5>(), make_variant<10>(), make_variant<20>()};
 
-const variant* pick_variant(int Wc, int Wo, int vslots = SWB_VSLOTS) {
+const variant* pick_variant(int Wc) {
   for (const variant& v : kVariants)
-    if (32 * v.nw >= Wc && 64 * v.ncol >= Wo && v.vs >= vslots) return &v;
+    if (32 * v.nw >= Wc) return &v;
   return nullptr;
 }
 
-// LDS bytes of one wave (= one environment) of variant v: wave_lds + edge records + span lists.  The
+kernel_fn pick_resample(int AA, int vslots, int* vs_out) {
+  if (AA == 1) { if (vs_out) *vs_out = 0; return swb_fill_kernel; }
+  if (vslots <= 6) { if (vs_out) *vs_out = 6; return swb_resample_kernel<6>; }
+  if (vs_out) *vs_out = 8;
+  return swb_resample_kernel<8>;
+}
+
+// LDS bytes of one wave (= one environment) of the cover kernel: wave_lds + edge records + span lists.  The
 // centred paths (16 B per vertex) borrow the idle mask arrays, or the edge records' storage.
 size_t lds_per_wave(const swb_engine* h, const variant* v, int* cpath_in_masks) {
   const swb_params& p = h->p;
   const size_t cpath_bytes = (size_t)p.max_edges * 16;
   const int in_masks = (2 * (size_t)SWB_NWA(v->nw) * SWB_WAVE * 4 >= cpath_bytes) ? 1 : 0;
   if (cpath_in_masks) *cpath_in_masks = in_masks;
-  (void)cpath_bytes;      // when not in the masks, the centred paths live in the edge records' storage (same 16 B per index)
   return (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
           (size_t)p.max_spans * SWB_WAVE * 4 + 15) & ~(size_t)15;
 }
 
-// Overflow slots for the span lists: one per wave that can be resident at once (occupancy of this
-// variant with its LDS footprint x CUs, capped by the batch), never one per environment.
-int ensure_overflow_slots(swb_engine* h, const variant* v, size_t lds_bytes) {
+// Overflow slots for the span lists of the cover kernel: one per wave that can be resident at once (occupancy of
+// the kernel that will be launched with its LDS footprint x CUs, capped by the batch), never one per environment.
+int ensure_overflow_slots(swb_engine* h, kernel_fn fn, size_t lds_bytes) {
   if (h->d_ovf) return 0;
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(v->fn), SWB_WAVE * SWB_WAVES_PER_BLOCK,
-                                                   lds_bytes) != hipSuccess || per_cu < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), SWB_WAVE, lds_bytes) != hipSuccess ||
+      per_cu < 1)
     per_cu = 32;
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-  long long slots = (long long)per_cu * SWB_WAVES_PER_BLOCK * cus;
+  long long slots = (long long)per_cu * cus;
   slots = std::min<long long>(2 * slots, (long long)h->p.N);              // the bitmap stays at most half full: few retries
   slots = (slots + 31) / 32 * 32;
   h->ovf_slots = (int)slots;
@@ -165,15 +172,84 @@ int ensure_overflow_slots(swb_engine* h, const variant* v, size_t lds_bytes) {
   return 0;
 }
 
+// Bands of output rows, the rows at which a run must end, and the canvas columns each group of 64 output columns
+// can see -- from the resampling tables (anti_aliasing > 1) or the identity (anti_aliasing = 1).
+int ensure_handoff_tables(swb_engine* h) {
+  if (!h->tables_dirty) return 0;
+  swb_params& p = h->p;
+  int nb = h->nbands;
+  p.ncg = (p.Wo + 63) / 64;
+  // Bands: about Ho / nb rows each; for the resample kernel the first row of a band is moved so that the number of
+  // output rows in flight at its first canvas row is a multiple of VS (the band's oldest row then sits in slot 0).
+  int vs = 0;
+  (void)pick_resample(p.AA, h->vslots, &vs);
+  auto first_in_flight = [&](int o_lo) {
+    int f = o_lo;
+    while (f > 0 && h->v_end_host[f - 1] >= h->v_ymin_host[o_lo]) --f;
+    return f;
+  };
+  std::vector<int32_t> blo(1, 0);
+  for (int b = 1; b < nb; ++b) {
+    int want = (int)((long long)b * p.Ho / nb), best = -1;
+    if (p.AA == 1) best = want;
+    else
+      for (int d = 0; d < p.Ho && best < 0; ++d)
+        for (int c : {want + d, want - d})
+          if (c > blo.back() && c < p.Ho && first_in_flight(c) % vs == 0) { best = c; break; }
+    if (best > blo.back() && best < p.Ho) blo.push_back(best);
+  }
+  nb = (int)blo.size();
+  blo.push_back(p.Ho);
+  p.nbands = nb;
+  std::vector<int32_t> y0(nb, 0), first(nb, 0), lo(p.ncg, 0), hi(p.ncg, 0);
+  std::vector<uint32_t> brk((size_t)(p.Hc + 31) / 32, 0u);
+  auto set_break = [&](int y) { if (y >= 0 && y < p.Hc) brk[y >> 5] |= 1u << (y & 31); };
+  for (int b = 0; b < nb; ++b) {
+    const int o_lo = blo[b];
+    if (p.AA == 1) { y0[b] = o_lo; first[b] = o_lo; }
+    else { y0[b] = h->v_ymin_host[o_lo]; first[b] = first_in_flight(o_lo); }
+    set_break(y0[b]);
+  }
+  if (p.AA != 1)
+    for (int o = 0; o < p.Ho; ++o) set_break(h->v_end_host[o] + 1);
+  for (int g = 0; g < p.ncg; ++g) {
+    if (p.AA == 1) { lo[g] = 64 * g; hi[g] = std::min(64 * g + 64, p.Wo); continue; }
+    lo[g] = 1 << 30; hi[g] = 0;
+    for (int o = 64 * g; o < std::min(64 * g + 64, p.Wo); ++o) {
+      lo[g] = std::min(lo[g], h->h_xmin_host[o]);
+      hi[g] = std::max(hi[g], h->h_xmin_host[o] + h->h_cnt_host[o]);
+    }
+  }
+  if (upload(&h->d_band_y0, y0.data(), y0.size()) || upload(&h->d_band_first, first.data(), first.size()) ||
+      upload(&h->d_band_lo, blo.data(), blo.size()) ||
+      upload(&h->d_v_break, brk.data(), brk.size()) || upload(&h->d_cg_lo, lo.data(), lo.size()) ||
+      upload(&h->d_cg_hi, hi.data(), hi.size()))
+    return SWB_ERR_HIP;
+  p.band_lo = h->d_band_lo;
+  p.band_y0 = h->d_band_y0; p.band_first = h->d_band_first; p.v_break = h->d_v_break; p.cg_lo = h->d_cg_lo; p.cg_hi = h->d_cg_hi;
+  // run lists: run_cap units of 8 bytes per (environment, column group) + 4 units of slack behind each list (the
+  // resample kernel reads a run's first 16 bytes in one go)
+  if (!h->d_runs) {
+    if (upload(&h->d_runs, (const uint32_t*)nullptr, ((size_t)p.N * p.ncg * p.run_cap + 4) * 2)) return SWB_ERR_HIP;
+    if (upload(&h->d_rhdr, (const uint32_t*)nullptr, (size_t)p.N * SWB_RHDR_DWORDS)) return SWB_ERR_HIP;
+    p.runs = h->d_runs; p.rhdr = h->d_rhdr;
+  }
+  h->tables_dirty = false;
+  return 0;
+}
+
 int flush_timing(swb_engine* h) {
   for (auto& ev : h->events) {
-    HIP_TRY(hipEventSynchronize(ev.second));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+    HIP_TRY(hipEventSynchronize(ev.e2));
+    float ms = 0.f, ms_cover = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e2));
+    HIP_TRY(hipEventElapsedTime(&ms_cover, ev.e0, ev.e1));
     h->timed_ms += ms;
+    h->timed_cover_ms += ms_cover;
     h->timed_launches += 1;
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
+    (void)hipEventDestroy(ev.e0);
+    (void)hipEventDestroy(ev.e1);
+    (void)hipEventDestroy(ev.e2);
   }
   h->events.clear();
   return 0;
@@ -185,10 +261,13 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   const swb_config& c = h->cfg;
   if (c.anti_aliasing != 1 && !(h->have_h && h->have_v))
     return fail(SWB_ERR_STATE, "swb_upload_resample (both axes) is required when anti_aliasing > 1");
-  const variant* v = pick_variant(h->p.Wc, h->p.Wo, h->vslots);
-  if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d / image width %d not supported", h->p.Wc, h->p.Hc, h->p.Wo);
+  const variant* v = pick_variant(h->p.Wc);
+  if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d not supported", h->p.Wc, h->p.Hc);
+  if (int rc = ensure_handoff_tables(h)) return rc;
+  int vs = 0;
+  const kernel_fn fn2 = pick_resample(h->p.AA, h->vslots, &vs);
   swb_params p = h->p;
-  if (p.v_tab && v->vs == 8) {                                        // slot tables of this variant's VS
+  if (p.v_tab && vs == 8) {                                           // slot tables of this VS
     p.v_tab += (size_t)p.Hc * SWB_VSLOTS;
     p.v_pfx += (size_t)(p.Hc + 1) * SWB_VSLOTS;
   }
@@ -201,41 +280,73 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   p.error = out ? out->error : nullptr;
   p.render_only = render_only;
   if (!render_only && actions == nullptr) return fail(SWB_ERR_INVALID, "actions is NULL");
-  const size_t pfx_bytes = ((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15;
   int cpath_in_masks = 0;
-  const size_t per_wave = lds_per_wave(h, v, &cpath_in_masks);
+  const size_t lds = lds_per_wave(h, v, &cpath_in_masks);
   p.cpath_in_masks = cpath_in_masks;
-  p.lds_per_wave = (int32_t)per_wave;
+  p.lds_per_wave = (int32_t)lds;
   p.outrow_bytes = (int32_t)v->outrow_bytes;
-  size_t lds = pfx_bytes + per_wave * SWB_WAVES_PER_BLOCK;
-  if (const char* x = getenv("SWB_EXTRA_LDS")) lds += (size_t)atoi(x);      // occupancy experiments only (tools/r02_occ.sh)
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
   // engines on which a sprite setter has been called run the build that reads the per-environment overrides
   const kernel_fn fn = h->d_ov_flag ? v->fn_ov : v->fn;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (!h->d_ovf || (int)lds < h->ovf_lds_bytes) {      // first launch, or a new pool shrank the LDS footprint (more waves resident)
+  // first launch, a new pool that shrank the LDS footprint (more waves resident), or the switch to the override build
+  if (!h->d_ovf || (int)lds < h->ovf_lds_bytes || fn != h->ovf_fn) {
     if (h->d_ovf) {
       HIP_TRY(hipDeviceSynchronize());
       (void)hipFree(h->d_ovf); (void)hipFree(h->d_ovf_bitmap);
       h->d_ovf = nullptr; h->d_ovf_bitmap = nullptr;
     }
-    if (int rc = ensure_overflow_slots(h, v, lds)) return rc;
+    if (int rc = ensure_overflow_slots(h, fn, lds)) return rc;
     h->ovf_lds_bytes = (int)lds;
+    h->ovf_fn = fn;
     p.ovf = h->p.ovf; p.ovf_bitmap = h->p.ovf_bitmap; p.ovf_slots = h->p.ovf_slots;
   }
-  const int blocks = (c.n_envs + SWB_WAVES_PER_BLOCK - 1) / SWB_WAVES_PER_BLOCK;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  swb_engine::step_events ev = {nullptr, nullptr, nullptr};
   if (h->timing) {
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, stream));
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
+    HIP_TRY(hipEventCreate(&ev.e2));
+    HIP_TRY(hipEventRecord(ev.e0, stream));
   }
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(SWB_WAVE * SWB_WAVES_PER_BLOCK), lds, stream, p);
-  HIP_TRY(hipGetLastError());
+  const size_t lds2 = p.AA == 1 ? 0 : (((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15);
+  auto launch_cover = [&](int e0, int e1) {
+    p.env_base = e0; p.env_end = e1;
+    hipLaunchKernelGGL(fn, dim3(e1 - e0), dim3(SWB_WAVE), lds, stream, p);
+  };
+  auto launch_resample = [&](int e0, int e1, hipStream_t st) {
+    p.env_base = e0; p.env_end = e1;
+    const dim3 grid((e1 - e0 + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK, p.nbands, p.ncg);
+    hipLaunchKernelGGL(fn2, grid, dim3(SWB_WAVE * SWB_RS_WAVES_PER_BLOCK), lds2, st, p);
+  };
+  const int G = (p.obs && h->stream2) ? std::min(h->groups, c.n_envs) : 1;
+  if (G <= 1) {
+    launch_cover(0, c.n_envs);
+    HIP_TRY(hipGetLastError());
+    if (h->timing) HIP_TRY(hipEventRecord(ev.e1, stream));
+    if (p.obs) launch_resample(0, c.n_envs, stream);
+    HIP_TRY(hipGetLastError());
+  } else {
+    int bounds[5];
+    for (int g = 0; g <= G; ++g) bounds[g] = (int)((long long)c.n_envs * g / G);
+    if (h->group_first > 0 && h->group_first < c.n_envs && G == 2) bounds[1] = h->group_first;
+    for (int g = 0; g < G; ++g) {
+      launch_cover(bounds[g], bounds[g + 1]);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(h->ev_cover[g], stream));
+    }
+    if (h->timing) HIP_TRY(hipEventRecord(ev.e1, stream));          // (end of the last cover kernel: the split is nominal)
+    for (int g = 0; g < G; ++g) {
+      HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_cover[g], 0));
+      launch_resample(bounds[g], bounds[g + 1], h->stream2);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
+    HIP_TRY(hipStreamWaitEvent(stream, h->ev_join, 0));
+  }
   if (h->timing) {
-    HIP_TRY(hipEventRecord(e1, stream));
-    h->events.emplace_back(e0, e1);
+    HIP_TRY(hipEventRecord(ev.e2, stream));
+    h->events.push_back(ev);
     if (h->events.size() >= 4096) return flush_timing(h);
   }
   return 0;
@@ -283,9 +394,33 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   p.n_tasks = cfg->n_tasks; p.is_meta = cfg->is_meta; p.meta_aggregator = cfg->meta_aggregator;
   p.meta_termination = cfg->meta_termination; p.meta_terminate_bonus = cfg->meta_terminate_bonus;
   memcpy(p.tasks, cfg->tasks, sizeof(p.tasks));
-  if (const char* dbg = getenv("SWB_DEBUG_PHASE")) p.debug_phase = atoi(dbg);
   if (p.Wc > 1023 || p.Hc > 65535) { delete h; return fail(SWB_ERR_INVALID, "canvas %dx%d too large", p.Wc, p.Hc); }
-  if (!pick_variant(p.Wc, p.Wo)) { delete h; return fail(SWB_ERR_INVALID, "canvas width %d / image width %d not supported", p.Wc, p.Wo); }
+  if (!pick_variant(p.Wc)) { delete h; return fail(SWB_ERR_INVALID, "canvas width %d not supported", p.Wc); }
+  if (p.Wo > 64 * SWB_MAX_CG) { delete h; return fail(SWB_ERR_INVALID, "image width %d not supported (max %d)", p.Wo, 64 * SWB_MAX_CG); }
+  // Bands of output rows per (environment, column group) in the second kernel: a band repeats the 25 canvas rows it
+  // shares with the band above, so there are only as many as it takes to give every SIMD its eight waves (small
+  // batches), in bands of at least 16 rows.
+  {
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const long long resident = (long long)std::max(cus, 1) * 4 * SWB_RS_WAVES_PER_SIMD;
+    const long long tasks = (long long)p.N * ((p.Wo + 63) / 64);
+    int nb = 1;
+    while (nb < SWB_MAX_BANDS && tasks * nb < resident && p.Ho / (2 * nb) >= 16) nb *= 2;
+    if (const char* x = getenv("SWB_BANDS")) nb = std::max(1, std::min(atoi(x), (int)SWB_MAX_BANDS));
+    h->nbands = std::min(nb, p.Ho);
+  }
+  // run lists: 8-byte units per (environment, column group); a canvas row costs 1 unit (one span), 2 (two or three)
+  // or more, and rows that repeat the row above cost nothing
+  if (const char* x = getenv("SWB_GROUPS")) h->groups = std::max(1, std::min(atoi(x), 4));
+  if (const char* x = getenv("SWB_GROUP_FIRST")) h->group_first = atoi(x);
+  if (h->groups > 1) {
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { h->stream2 = nullptr; h->groups = 1; }
+    for (int g = 0; g < 4 && h->stream2; ++g) (void)hipEventCreateWithFlags(&h->ev_cover[g], hipEventDisableTiming);
+    if (h->stream2) (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+  }
+  p.run_cap = 4 * p.Hc;
+  if (const char* x = getenv("SWB_RUN_CAP")) p.run_cap = std::max(8, atoi(x));      // tests
   const size_t NS = (size_t)p.N * p.S;
   int rc = 0;
   rc |= upload(&h->d_x, (const double*)nullptr, NS);
@@ -313,12 +448,19 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
 int swb_destroy(swb_handle h) {
   if (!h) return SWB_OK;
   (void)hipSetDevice(h->device);
-  for (auto& ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto& ev : h->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
+  if (h->stream2) {
+    (void)hipStreamSynchronize(h->stream2);
+    for (hipEvent_t e : h->ev_cover) if (e) (void)hipEventDestroy(e);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    (void)hipStreamDestroy(h->stream2);
+  }
   void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
                   h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler,
-                  h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label};
+                  h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label,
+                  h->d_runs, h->d_rhdr, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;
@@ -386,6 +528,8 @@ int swb_upload_resample(swb_handle h, int32_t axis, int32_t out_size, int32_t ks
       return SWB_ERR_HIP;
     h->p.h_xmin = h->d_h_xmin; h->p.h_cnt = h->d_h_cnt; h->p.h_tbl = h->d_h_tbl; h->p.h_pfx = h->d_h_pfx;
     h->p.h_pfx_len = (int32_t)pfx.size();
+    h->h_xmin_host = xmin; h->h_cnt_host = cnt;
+    h->tables_dirty = true;
     h->have_h = true;
   } else if (axis == 1) {
     if (out_size != p.Ho) return fail(SWB_ERR_INVALID, "vertical table has %d outputs, image height is %d", out_size, p.Ho);
@@ -424,11 +568,17 @@ int swb_upload_resample(swb_handle h, int32_t axis, int32_t out_size, int32_t ks
         for (int k = 0; k < SWB_VSLOTS; ++k)
           vpfx[t * pfx_len + (size_t)(y + 1) * SWB_VSLOTS + k] =
               vpfx[t * pfx_len + (size_t)y * SWB_VSLOTS + k] + vtab[t * tab_len + (size_t)y * SWB_VSLOTS + k];
-    if (upload(&h->d_v_tab, vtab.data(), vtab.size()) || upload(&h->d_v_end, vend.data(), vend.size()) ||
+    std::vector<int32_t> vend_padded(vend);
+    vend_padded.push_back(0x7fffffff); vend_padded.push_back(0x7fffffff);       // the resample kernel loads one row ahead
+    if (upload(&h->d_v_tab, vtab.data(), vtab.size()) || upload(&h->d_v_end, vend_padded.data(), vend_padded.size()) ||
         upload(&h->d_v_pfx, vpfx.data(), vpfx.size()))
       return SWB_ERR_HIP;
     h->p.v_tab = h->d_v_tab; h->p.v_end = h->d_v_end; h->p.v_pfx = h->d_v_pfx;
     h->vslots = used;
+    h->v_end_host = vend;
+    h->v_ymin_host.resize(out_size);
+    for (int r = 0; r < out_size; ++r) h->v_ymin_host[r] = bounds[2 * r];
+    h->tables_dirty = true;
     h->have_v = true;
   } else {
     return fail(SWB_ERR_INVALID, "axis must be 0 or 1");
@@ -910,11 +1060,17 @@ int swb_get_sprite(swb_handle h, int32_t env, int32_t sprite, int32_t* shape, do
 
 int swb_variant(swb_handle h, swb_variant_info* out) {
   if (!h || !out) return fail(SWB_ERR_INVALID, "null argument");
-  const variant* v = pick_variant(h->p.Wc, h->p.Wo, h->vslots);
-  if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d / image width %d not supported", h->p.Wc, h->p.Hc, h->p.Wo);
-  out->nw = v->nw; out->ncol = v->ncol; out->vs = v->vs;
+  const variant* v = pick_variant(h->p.Wc);
+  if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d not supported", h->p.Wc, h->p.Hc);
+  int vs = 0;
+  (void)pick_resample(h->p.AA, h->vslots, &vs);
+  out->nw = v->nw; out->ncol = 1; out->vs = vs;
   out->lds_bytes_per_wave = (int32_t)lds_per_wave(h, v, nullptr);
-  out->waves_per_simd = v->ncol == 1 ? SWB_WAVES_PER_SIMD : (v->ncol == 2 ? SWB_WAVES_PER_SIMD_2COL : 1);
+  out->waves_per_simd = v->nw <= 10 ? SWB_COVER_WAVES_PER_SIMD : SWB_COVER_WAVES_PER_SIMD_WIDE;
+  out->resample_waves_per_simd = SWB_RS_WAVES_PER_SIMD;
+  out->n_bands = h->p.nbands ? h->p.nbands : h->nbands;
+  out->n_column_groups = (h->p.Wo + 63) / 64;
+  out->run_cap = h->p.run_cap;
   return SWB_OK;
 }
 
@@ -929,6 +1085,7 @@ int swb_timing_enable(swb_handle h, int32_t enable) {
   if (flush_timing(h)) return SWB_ERR_HIP;
   h->timing = enable != 0;
   h->timed_ms = 0.0;
+  h->timed_cover_ms = 0.0;
   h->timed_launches = 0;
   return SWB_OK;
 }
@@ -938,6 +1095,16 @@ int swb_step_time_ms(swb_handle h, double* total_ms, int64_t* launches) {
   HIP_TRY(hipSetDevice(h->device));
   if (flush_timing(h)) return SWB_ERR_HIP;
   if (total_ms) *total_ms = h->timed_ms;
+  if (launches) *launches = h->timed_launches;
+  return SWB_OK;
+}
+
+int swb_kernel_times_ms(swb_handle h, double* cover_ms, double* resample_ms, int64_t* launches) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if (flush_timing(h)) return SWB_ERR_HIP;
+  if (cover_ms) *cover_ms = h->timed_cover_ms;
+  if (resample_ms) *resample_ms = h->timed_ms - h->timed_cover_ms;
   if (launches) *launches = h->timed_launches;
   return SWB_OK;
 }

@@ -189,7 +189,8 @@ class Engine(object):
     info = _abi.SwbVariantInfo()
     _lib.check(self.lib.swb_variant(self._h, C.byref(info)))
     d = {k: getattr(info, k) for k, _ in _abi.SwbVariantInfo._fields_}
-    d['kernel'] = 'swb_step_kernel<%d,%d,%d>' % (info.nw, info.ncol, info.vs)
+    d['cover_kernel'] = 'swb_cover_kernel<%d>' % info.nw
+    d['kernel'] = 'swb_resample_kernel<%d>' % info.vs if info.vs else 'swb_fill_kernel'
     d['build_id'] = self.lib.swb_build_id().decode()
     return d
 
@@ -200,3 +201,9 @@ class Engine(object):
     ms, n = C.c_double(0.0), C.c_int64(0)
     _lib.check(self.lib.swb_step_time_ms(self._h, C.byref(ms), C.byref(n)))
     return ms.value, n.value
+
+  def kernel_times_ms(self):
+    """(cover ms, resample / fill ms, launches) since timing(True): the step interval split between its two kernels."""
+    a, b, n = C.c_double(0.0), C.c_double(0.0), C.c_int64(0)
+    _lib.check(self.lib.swb_kernel_times_ms(self._h, C.byref(a), C.byref(b), C.byref(n)))
+    return a.value, b.value, n.value

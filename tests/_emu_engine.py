@@ -189,7 +189,8 @@ class EmuEngine(object):
     info = _abi.SwbVariantInfo()
     check(self.lib.swb_variant(self._h, C.byref(info)))
     d = {k: getattr(info, k) for k, _ in _abi.SwbVariantInfo._fields_}
-    d['kernel'] = 'swb_step_kernel<%d,%d,%d>' % (info.nw, info.ncol, info.vs)
+    d['cover_kernel'] = 'swb_cover_kernel<%d>' % info.nw
+    d['kernel'] = 'swb_resample_kernel<%d>' % info.vs if info.vs else 'swb_fill_kernel'
     d['build_id'] = self.lib.swb_build_id().decode()
     return d
 

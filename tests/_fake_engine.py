@@ -79,4 +79,4 @@ class FakeEngine(object):
     return torch.from_numpy(out)
 
   def variant(self):
-    return {'kernel': 'swb_step_kernel<oracle>', 'build_id': 'oracle'}
+    return {'kernel': 'swb_resample_kernel<oracle>', 'build_id': 'oracle'}

@@ -4,9 +4,7 @@ emulation shim (tests/emu/shim/hip/hip_runtime.h) -- TEST INFRASTRUCTURE ONLY, s
 The product sources are not edited for this.  Two constructs cannot be compiled for x86 and are rewritten in a
 temporary copy (each rewrite must match, else the build fails):
   * the four inline-assembly statements (v_med3_i32, three v_mad_i32_i24) -> their C meaning;
-  * the constant-address-space pointer alias (address_space(4), scalar loads on the GPU) -> a plain pointer;
-  * one store in davies_bouldin_wave that relies on the lanes of a wave running in lock step (a cross-lane
-    write-after-read on LDS without a fence) is moved behind a wave_sync().
+  * the constant-address-space pointer alias (address_space(4), scalar loads on the GPU) -> a plain pointer.
 """
 import hashlib
 import os
@@ -42,17 +40,6 @@ def _rewrite(text, name):
   text, n = re.subn(r'using cptr = const T __attribute__\(\(address_space\(4\)\)\)\*;', 'using cptr = const T*;   /* emu */', text)
   assert n == 1, 'constant address space alias not found'
   assert 'asm(' not in text.replace('asm("")', ''), 'an inline-assembly statement is left'
-  # Lock-step assumption the fibres cannot honour: davies_bouldin_wave zeroes sc->tmp[l] at the end of a block in which
-  # OTHER lanes still read sc->tmp[] (float64 positions only).  On the GPU the lanes of a wave execute every instruction
-  # together, so all reads of the loop come before the store; here lanes run one after the other between two
-  # rendezvous.  The store is moved behind a wave_sync() (same values; the product source should get the same
-  # treatment next time it is touched -- a cross-lane write-after-read hazard is worth a fence).
-  old = ("    sc->tmp[l] = 0.0;                                               // max_b ratio[a][b], filled below\n"
-         "  }\n  wave_sync();\n")
-  if text.count(old) == 1:
-    text = text.replace(old, "  }\n  wave_sync();\n  if (l < k) sc->tmp[l] = 0.0;   /* emu: after the fence */\n  wave_sync();\n")
-  else:       # sources that already carry the fence (tools/next_round/a_fence_davies_bouldin_war.patch)
-    assert 'if (l < k) sc->tmp[l] = 0.0;' in text, 'davies_bouldin_wave write-after-read site not found'
   if os.environ.get('SWB_EMU_STATS'):
     text = _instrument(text)
   return text

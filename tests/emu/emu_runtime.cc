@@ -144,13 +144,39 @@ const uint64_t* exchange(uint64_t in, int line, unsigned long long* active) {
   return w.table[buf];
 }
 
+// s_barrier: a work-item waits until every unfinished work-item of the workgroup has arrived (from the same source
+// line: a barrier under divergent control flow is refused like any other rendezvous).
+namespace {
+int g_bar_generation = 0, g_bar_arrived = 0, g_bar_line = -1;
+}
+void block_barrier(int line) {
+  const int gen = g_bar_generation;
+  if (g_bar_arrived == 0) g_bar_line = line;
+  else if (g_bar_line != line) {
+    fprintf(stderr, "emu: __syncthreads() under divergent control flow: source lines %d and %d\n", g_bar_line, line);
+    abort();
+  }
+  g_bar_arrived += 1;
+  while (g_bar_generation == gen) {
+    int alive = 0;
+    for (int t = 0; t < g_threads; ++t) alive += g_fibres[t].done ? 0 : 1;
+    if (g_bar_arrived >= alive) { g_bar_arrived = 0; g_bar_generation = gen + 1; break; }
+    g_current->waiting_gen = -2;              // parked in the block barrier: polled by the scheduler
+    yield_to_scheduler();
+  }
+  g_current->waiting_gen = -1;
+}
+
 void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes) {
   const int threads = (int)(block.x * block.y * block.z);
   if (threads > kMaxThreads || lds_bytes > sizeof(smem)) { fprintf(stderr, "emu: launch too large\n"); abort(); }
   if (g_current) { fprintf(stderr, "emu: nested launch\n"); abort(); }
   g_body = &body;
   g_threads = threads;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+  for (unsigned by = 0; by < grid.y; ++by)
   for (unsigned b = 0; b < grid.x; ++b) {
+    g_bar_generation = 0; g_bar_arrived = 0;
     // LDS is not initialised on the device: a garbage pattern (SWB_EMU_LDS_FILL overrides the byte, to check that no
     // result depends on what a previous workgroup left there)
     static const int fill = getenv("SWB_EMU_LDS_FILL") ? (int)strtol(getenv("SWB_EMU_LDS_FILL"), nullptr, 0) : 0xA5;
@@ -159,7 +185,7 @@ void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, size_t l
       fibre& f = g_fibres[t];
       prepare(f);
       f.st.tid = dim3((unsigned)t, 0, 0);
-      f.st.bid = dim3(b, 0, 0);
+      f.st.bid = dim3(b, by, bz);
       f.st.bdim = block;
       f.st.lane = t & 63;
     }

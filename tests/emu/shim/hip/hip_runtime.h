@@ -38,6 +38,8 @@ struct dim3 {
 struct double2 { double x, y; };
 inline double2 make_double2(double x, double y) { return double2{x, y}; }
 struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 // ---------------------------------------------------------------- the emulator core (tests/emu/emu_runtime.cc)
 namespace emu {
@@ -102,6 +104,7 @@ inline int update_dpp(int old, int src_val, int ctrl, int line) {
   return (s >= 0 && ((act >> s) & 1ull)) ? from_bits<int>(t[s]) : old;
 }
 inline void wave_barrier(int line) { unsigned long long act; (void)exchange(0, line, &act); }
+void block_barrier(int line);               // s_barrier: every unfinished work-item of the workgroup
 }  // namespace emu
 
 #define __ballot(p) emu::ballot((p), __LINE__)
@@ -113,7 +116,7 @@ inline void wave_barrier(int line) { unsigned long long act; (void)exchange(0, l
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl) emu::update_dpp((old), (src), (ctrl), __LINE__)
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier(__LINE__)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-#define __syncthreads() emu::wave_barrier(__LINE__)
+#define __syncthreads() emu::block_barrier(__LINE__)
 // v_perm_b32 D = bytes of {S0, S1} selected by S2: selector 0-3 = S1's bytes, 4-7 = S0's bytes (only these are used)
 inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel) {
   const uint64_t both = ((uint64_t)s0 << 32) | s1;
@@ -187,6 +190,12 @@ inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v 
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 16; return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+#define hipEventDisableTiming 2
+#define hipStreamNonBlocking 1
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static int token; *s = &token; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
