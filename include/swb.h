@@ -285,6 +285,11 @@ int swb_render(swb_handle h, uint8_t* obs_dev, void* stream);
  * constants.ShapeType value (1-based); rows >= n_sprites[env] are zero. */
 int swb_factors(swb_handle h, double* factors_dev, void* stream);
 
+/* Scalars of ONE environment (environment.py:74-108 keeps them as attributes): out5 = { sprites in the current
+ * episode, pool entry it plays, step count, episodes started, 1 if the next step is a reset }.  Synchronises
+ * `stream`; five 4-byte copies whatever the batch size (swb_get_state copies every environment). */
+int swb_get_env_state(swb_handle h, int32_t env, int32_t* out5, void* stream);
+
 /* Blocking state access (synchronises `stream`). */
 int swb_get_state(swb_handle h, const swb_state* host_state, void* stream);
 int swb_set_positions(swb_handle h, const double* x_host, const double* y_host, void* stream);

@@ -90,12 +90,10 @@ struct swb_engine {
   uint8_t* d_reset_next = nullptr;
   uint32_t *d_ovf = nullptr, *d_ovf_bitmap = nullptr;
   int ovf_slots = 0;
-  // A step may be issued as `groups` groups of environments: the cover kernels one after the other on the caller's
-  // stream, each group's resample kernel on an internal stream as soon as its cover kernel is done -- so that the
-  // latency-bound cover kernel of group g + 1 shares the machine with the ALU-bound resample kernel of group g.
-  int groups = 1, group_first = 0;   // group_first: environments in the first group (0: equal groups)
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_cover[4] = {nullptr, nullptr, nullptr, nullptr}, ev_join = nullptr;
+  // cost-ordered dispatch (swb_params::cost_cnt)
+  uint32_t* d_cost_cnt = nullptr;
+  int32_t* d_cost_list = nullptr;
+  int launch_parity = 0;
   // hand-off cover -> resample
   uint32_t *d_runs = nullptr, *d_rhdr = nullptr;
   int32_t *d_band_y0 = nullptr, *d_band_first = nullptr, *d_band_lo = nullptr, *d_cg_lo = nullptr, *d_cg_hi = nullptr;
@@ -202,7 +200,7 @@ int ensure_handoff_tables(swb_engine* h) {
   blo.push_back(p.Ho);
   p.nbands = nb;
   std::vector<int32_t> y0(nb, 0), first(nb, 0), lo(p.ncg, 0), hi(p.ncg, 0);
-  std::vector<uint32_t> brk((size_t)(p.Hc + 31) / 32, 0u);
+  std::vector<uint32_t> brk((size_t)(p.Hc + 31) / 32 + 3, 0u);      // (+3: a batch reads three words from its first row's word)
   auto set_break = [&](int y) { if (y >= 0 && y < p.Hc) brk[y >> 5] |= 1u << (y & 31); };
   for (int b = 0; b < nb; ++b) {
     const int o_lo = blo[b];
@@ -310,40 +308,26 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
     HIP_TRY(hipEventRecord(ev.e0, stream));
   }
   const size_t lds2 = p.AA == 1 ? 0 : (((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15);
+  p.parity = h->launch_parity;
+  // (cost-ordered: block b serves rank b / 8 of shard b % 8; a shard holds up to cost_cap environments)
   auto launch_cover = [&](int e0, int e1) {
-    p.env_base = e0; p.env_end = e1;
     hipLaunchKernelGGL(fn, dim3(e1 - e0), dim3(SWB_WAVE), lds, stream, p);
   };
   auto launch_resample = [&](int e0, int e1, hipStream_t st) {
-    p.env_base = e0; p.env_end = e1;
-    const dim3 grid((e1 - e0 + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK, p.nbands, p.ncg);
+    const int blocks_x = p.cost_cnt ? SWB_COST_SHARDS * ((p.cost_cap + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK)
+                                    : (e1 - e0 + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK;
+    const dim3 grid(blocks_x, p.nbands, p.ncg);
     hipLaunchKernelGGL(fn2, grid, dim3(SWB_WAVE * SWB_RS_WAVES_PER_BLOCK), lds2, st, p);
   };
-  const int G = (p.obs && h->stream2) ? std::min(h->groups, c.n_envs) : 1;
-  if (G <= 1) {
-    launch_cover(0, c.n_envs);
-    HIP_TRY(hipGetLastError());
-    if (h->timing) HIP_TRY(hipEventRecord(ev.e1, stream));
-    if (p.obs) launch_resample(0, c.n_envs, stream);
-    HIP_TRY(hipGetLastError());
-  } else {
-    int bounds[5];
-    for (int g = 0; g <= G; ++g) bounds[g] = (int)((long long)c.n_envs * g / G);
-    if (h->group_first > 0 && h->group_first < c.n_envs && G == 2) bounds[1] = h->group_first;
-    for (int g = 0; g < G; ++g) {
-      launch_cover(bounds[g], bounds[g + 1]);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(h->ev_cover[g], stream));
-    }
-    if (h->timing) HIP_TRY(hipEventRecord(ev.e1, stream));          // (end of the last cover kernel: the split is nominal)
-    for (int g = 0; g < G; ++g) {
-      HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_cover[g], 0));
-      launch_resample(bounds[g], bounds[g + 1], h->stream2);
-      HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
-    HIP_TRY(hipStreamWaitEvent(stream, h->ev_join, 0));
-  }
+  launch_cover(0, c.n_envs);
+  HIP_TRY(hipGetLastError());
+  if (h->timing) HIP_TRY(hipEventRecord(ev.e1, stream));
+  if (p.obs) launch_resample(0, c.n_envs, stream);
+  HIP_TRY(hipGetLastError());
+  if (!p.obs && p.cost_cnt)       // no second kernel to clear the next launch's bucket counters
+    HIP_TRY(hipMemsetAsync(h->d_cost_cnt + (size_t)(p.parity ^ 1) * SWB_COST_SHARDS * SWB_COST_BUCKETS, 0,
+                           SWB_COST_SHARDS * SWB_COST_BUCKETS * sizeof(uint32_t), stream));
+  h->launch_parity ^= 1;
   if (h->timing) {
     HIP_TRY(hipEventRecord(ev.e2, stream));
     h->events.push_back(ev);
@@ -412,12 +396,17 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   }
   // run lists: 8-byte units per (environment, column group); a canvas row costs 1 unit (one span), 2 (two or three)
   // or more, and rows that repeat the row above cost nothing
-  if (const char* x = getenv("SWB_GROUPS")) h->groups = std::max(1, std::min(atoi(x), 4));
-  if (const char* x = getenv("SWB_GROUP_FIRST")) h->group_first = atoi(x);
-  if (h->groups > 1) {
-    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { h->stream2 = nullptr; h->groups = 1; }
-    for (int g = 0; g < 4 && h->stream2; ++g) (void)hipEventCreateWithFlags(&h->ev_cover[g], hipEventDisableTiming);
-    if (h->stream2) (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+  // cost buckets: 32 of them over run lists of up to ~Hc units (longer lists share the last one)
+  p.cost_shift = 0;
+  while ((SWB_COST_BUCKETS << p.cost_shift) < p.Hc) ++p.cost_shift;
+  if (!getenv("SWB_NO_COST_ORDER")) {
+    p.cost_cap = (p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS;
+    if (upload(&h->d_cost_cnt, (const uint32_t*)nullptr, 2 * SWB_COST_SHARDS * SWB_COST_BUCKETS) ||
+        upload(&h->d_cost_list, (const int32_t*)nullptr, (size_t)2 * SWB_COST_SHARDS * SWB_COST_BUCKETS * p.cost_cap)) {
+      swb_destroy(h);
+      return SWB_ERR_HIP;
+    }
+    p.cost_cnt = h->d_cost_cnt; p.cost_list = h->d_cost_list;
   }
   p.run_cap = 4 * p.Hc;
   if (const char* x = getenv("SWB_RUN_CAP")) p.run_cap = std::max(8, atoi(x));      // tests
@@ -449,18 +438,12 @@ int swb_destroy(swb_handle h) {
   if (!h) return SWB_OK;
   (void)hipSetDevice(h->device);
   for (auto& ev : h->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
-  if (h->stream2) {
-    (void)hipStreamSynchronize(h->stream2);
-    for (hipEvent_t e : h->ev_cover) if (e) (void)hipEventDestroy(e);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    (void)hipStreamDestroy(h->stream2);
-  }
   void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
                   h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler,
                   h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label,
-                  h->d_runs, h->d_rhdr, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
+                  h->d_cost_cnt, h->d_cost_list, h->d_runs, h->d_rhdr, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;
@@ -851,6 +834,21 @@ int swb_get_state(swb_handle h, const swb_state* st, void* stream) {
   return SWB_OK;
 }
 
+int swb_get_env_state(swb_handle h, int32_t env, int32_t* out5, void* stream) {
+  if (!h || !out5) return fail(SWB_ERR_INVALID, "null argument");
+  if (env < 0 || env >= h->p.N) return fail(SWB_ERR_INVALID, "environment %d out of range", env);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  uint8_t rn = 0;
+  HIP_TRY(hipMemcpy(&out5[0], h->d_nspr + env, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&out5[1], h->d_entry + env, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&out5[2], h->d_step_count + env, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&out5[3], h->d_episode + env, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&rn, h->d_reset_next + env, 1, hipMemcpyDeviceToHost));
+  out5[4] = rn;
+  return SWB_OK;
+}
+
 int swb_set_positions(swb_handle h, const double* x_host, const double* y_host, void* stream) {
   if (!h || !x_host || !y_host) return fail(SWB_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(h->device));
@@ -925,7 +923,9 @@ int ov_allocate(swb_engine* h) {
 
 // The record of environment `env`: its override arrays when the flag is set, else built from its pool entry
 // (fresh centred paths, sprite.py:96-101).  `n` receives the episode's sprite count.
-int ov_fetch(swb_engine* h, int env, env_override* r, int* n, bool* was_set) {
+// `for_write`: a setter needs a running episode; reading the sprites of an episode that has just ended (the
+// reference's sprites stay readable until the next reset) is fine.
+int ov_fetch(swb_engine* h, int env, env_override* r, int* n, bool* was_set, bool for_write = true) {
   const int S = h->p.S, T = h->p.n_tasks;
   r->shape.assign(S, 0); r->scale.assign(S, 1.0); r->angle.assign(S, 0.0);
   r->cpath.assign((size_t)S * SWB_MAX_SHAPE_VERTS * 2, 0.0); r->label.assign((size_t)T * S, 0);
@@ -938,7 +938,8 @@ int ov_fetch(swb_engine* h, int env, env_override* r, int* n, bool* was_set) {
   int32_t ep = 0;
   HIP_TRY(hipMemcpy(&ep, h->d_episode + env, 4, hipMemcpyDeviceToHost));
   if (ep == 0) return fail(SWB_ERR_STATE, "environment %d has not been reset yet: it has no sprites", env);
-  if (rn) return fail(SWB_ERR_STATE, "environment %d is about to reset (its episode ended): its sprites are gone at the next step", env);
+  if (rn && for_write)
+    return fail(SWB_ERR_STATE, "environment %d is about to reset (its episode ended): its sprites are gone at the next step", env);
   *n = ns;
   *was_set = flag != 0;
   const size_t o = (size_t)env * S, pe = (size_t)en * S;
@@ -1047,7 +1048,7 @@ int swb_get_sprite(swb_handle h, int32_t env, int32_t sprite, int32_t* shape, do
   env_override r;
   int n = 0;
   bool was_set = false;
-  if (int rc = ov_fetch(h, env, &r, &n, &was_set)) return rc;
+  if (int rc = ov_fetch(h, env, &r, &n, &was_set, false)) return rc;
   if (sprite < 0 || sprite >= n) return fail(SWB_ERR_INVALID, "environment %d has %d sprites: sprite %d out of range", env, n, sprite);
   const int nv = h->shape_nverts[r.shape[sprite]];
   if (shape) *shape = r.shape[sprite];

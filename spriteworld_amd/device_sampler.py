@@ -196,6 +196,15 @@ class DeviceSampler(object):
                           'generator on the host instead' % sorted(labels))
     return labels.pop()
 
+  def scale_kinds(self):
+    """swb_factor kind of every group's `scale` factor (FACTOR_UNIFORM_F32: the sprites carry np.float32 scales)."""
+    kinds = []
+    for _, _, _, marg in self.groups:
+      fac = _abi.SwbFactor()
+      _lower_factor(fac, 'scale', marg.get('scale'))
+      kinds.append(fac.kind)
+    return kinds
+
   def lower(self, task, renderers):
     from spriteworld_amd import lowering
     spec = _abi.SwbSampler()

@@ -155,6 +155,13 @@ class Engine(object):
     _lib.check(self.lib.swb_get_state(self._h, C.byref(cs), self._stream()))
     return st
 
+  def env_state(self, env):
+    """dict(n_sprites, pool_entry, step_count, episode, reset_next) of ONE environment (swb_get_env_state: a few bytes,
+    whatever the batch size)."""
+    out = np.zeros(5, np.int32)
+    _lib.check(self.lib.swb_get_env_state(self._h, int(env), _ptr(out), self._stream()))
+    return dict(zip(('n_sprites', 'pool_entry', 'step_count', 'episode', 'reset_next'), (int(v) for v in out)))
+
   def set_positions(self, x, y):
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)

@@ -81,9 +81,7 @@ class BatchedEnvironment(object):
     # refresh_pool() can be called by hand).  episodes_per_env * shortest episode length is a safe period.
     # 'auto': 2 * (episodes_per_env - 1) steps -- an episode lasts at least two steps (FIRST + one more), so no
     # environment can run out of unseen entries between two refreshes.
-    if refresh_every == 'auto':
-      refresh_every = 2 * (self._episodes_per_env - 1)
-    self._refresh_every = int(refresh_every)
+    self._refresh_every = 2 * (self._episodes_per_env - 1) if refresh_every == 'auto' else int(refresh_every)
     self._steps_since_refresh = 0
     self._image_key, self._pil = lowering.find_pil_renderer(renderers)
     self._success_keys = [k for k, r in renderers.items() if type(r).__name__ == 'Success']
@@ -99,15 +97,20 @@ class BatchedEnvironment(object):
     self._sampler = init_sprites if isinstance(init_sprites, device_sampler.DeviceSampler) else None
     if self._sampler is None and device_reset:
       try:
-        # `seed` keys the Philox episode streams; None draws it from numpy's global stream, so np.random.seed()
-        # makes runs reproducible and different seeds give different episodes
-        sampler = device_sampler.from_generator(
-            init_sprites, seed=int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed))
+        sampler = device_sampler.from_generator(init_sprites, seed=0)
         sampler.lower(task, renderers)
+        # `seed` keys the Philox episode streams; None draws it from numpy's global stream, so np.random.seed()
+        # makes runs reproducible and different seeds give different episodes.  Drawn only once the generator is
+        # known to lower: a generator that falls back to the host path sees numpy's stream untouched.
+        sampler.seed = int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed)
         self._sampler = sampler
       except lowering.LoweringError:
         if device_reset != 'auto':
           raise
+    if self._sampler is not None and self._episodes_per_env < 2 and refresh_every == 'auto':
+      import warnings
+      warnings.warn('device-side reset sampling with episodes_per_env=1 cannot refresh the pool while it is in use: every '
+                    'environment replays its one episode (raise episodes_per_env, or call refill_pool() yourself)')
     if self._sampler is not None:   # episodes are drawn by the engine (swb_sample_pool)
       episodes = None
       S = max_sprites or max(self._sampler.max_sprites, 1)
@@ -117,11 +120,15 @@ class BatchedEnvironment(object):
       S = max_sprites or max([len(ep) for ep in episodes] + [1])
       pos_dt = lowering.position_dtype(episodes)
     self._max_sprites = S
+    # SelectMove noise (action_spaces.py:69-75) is added to the action tensor on the device.  `action +
+    # np.random.normal(...)` is float64 whatever the action's dtype (array + float64 array), so a noisy action
+    # space always runs the engine's float64-action arithmetic.
+    ns = getattr(action_space, '_noise_scale', None)
+    if ns:
+      action_dtype = np.float64
     self._cfg = lowering.lower_config(task, action_space, renderers, keep_in_frame,
                                       max_episode_length, self._num_envs, S,
                                       pos_is_f32=(pos_dt == np.float32), action_dtype=action_dtype)
-    # SelectMove noise (action_spaces.py:69-75) is added to the action tensor on the device
-    ns = getattr(action_space, '_noise_scale', None)
     self._noise_scale = None if not ns else torch.as_tensor(np.asarray(ns, dtype=np.float64))
     self._noise_gen = None
     if self._sampler is not None:
@@ -133,6 +140,7 @@ class BatchedEnvironment(object):
       pool.assign_round_robin(self._num_envs, self._episodes_per_env)
       self._engine = _engine.Engine(self._cfg, pool, device=device)
     self._render = self._pil is not None
+    self._attr_assigned = {}      # (env, sprite, 'angle' | 'scale') -> (episode, the assigned value was an np.float32)
 
   # ------------------------------------------------------------------ pool
   def _draw_episodes(self):
@@ -246,9 +254,9 @@ class BatchedEnvironment(object):
       e = self._engine
       if not isinstance(actions, torch.Tensor):
         actions = torch.as_tensor(np.ascontiguousarray(actions))
-      actions = actions.to(device=e.device, dtype=torch.float32 if self._cfg.action_is_f32 else torch.float64)
+      actions = actions.to(device=e.device)
       noise = torch.randn(actions.shape, dtype=torch.float64, device=e.device, generator=self._noise_gen)
-      actions = (actions.to(torch.float64) + noise * self._noise_scale.to(e.device)).to(actions.dtype)
+      actions = actions.to(torch.float64) + noise * self._noise_scale.to(e.device)      # float64 from here on (see __init__)
     self._engine.step(actions, render=self._render)
     if self._refresh_every and self._sampler is not None:
       self._steps_since_refresh += 1
@@ -278,7 +286,7 @@ class BatchedEnvironment(object):
     """The sprites of environment `env` in its current episode, back to front, as `sprite.LiveSprite` handles
     (the reference's `env.state()['sprites']`): `env.sprites(3)[0].angle = 45` acts on the device state."""
     from spriteworld_amd import sprite as sprite_lib
-    n = int(self._engine.state()['n_sprites'][env])
+    n = self._engine.env_state(env)['n_sprites']
     return [sprite_lib.LiveSprite(self, env, k) for k in range(n)]
 
   def set_sprite_attr(self, env, sprite, name, value):
@@ -293,8 +301,39 @@ class BatchedEnvironment(object):
     factors[name] = value
     proxy = collections.namedtuple('_Factors', ['factors'])(factors)
     label = np.array([lowering._label_of(sub, proxy) for sub in lowering.subtasks_of(self._task)], dtype=np.int8)  # pylint: disable=protected-access
+    delta = None
+    episode = self._engine.env_state(env)['episode']
+    if name != 'shape':
+      # sprite.py:163,173 take `a - self._angle` / `s - self._scale` with whatever types the two carry: an np.float32
+      # attribute (factor distributions draw float32) makes it a float32 subtraction under NEP 50.  numpy decides here too.
+      old = getattr(live, name)
+      old = np.float32(old) if self._attr_is_f32(env, sprite, name, episode, old) else float(old)
+      delta = float(value - old)
     self._engine.set_sprite_attr(env, sprite, attr, shapes_lib.shape_index(value) if name == 'shape' else float(value),
-                                 label=label)
+                                 delta=delta, label=label)
+    if name != 'shape':           # from now on the attribute is the object the caller assigned
+      self._attr_assigned[(env, sprite, name)] = (episode, getattr(value, 'dtype', None) == np.float32)
+
+  def _attr_is_f32(self, env, sprite, name, episode, value):
+    """Is this sprite's angle / scale an np.float32 in the reference?  A value assigned through a setter keeps the
+    type it was given; factor distributions draw float32, Discrete candidates and Sprite() defaults are Python numbers.
+    Host pools record it per sprite; with a device sampler angles are never float32 (Discrete or integer degrees only)
+    and a scale is when every group draws it from a Continuous distribution (generators that mix both: when the current
+    value is float32-representable)."""
+    rec = self._attr_assigned.get((env, sprite, name))
+    if rec is not None and rec[0] == episode:
+      return rec[1]
+    pool = self._engine.pool
+    if pool is not None and getattr(pool, 'attr_f32', None) is not None:
+      return bool(pool.attr_f32[self._engine.env_state(env)['pool_entry'], sprite] & (1 if name == 'angle' else 2))
+    if self._sampler is None or name == 'angle':
+      return False
+    kinds = self._sampler.scale_kinds()
+    if all(k == _abi.FACTOR_UNIFORM_F32 for k in kinds):
+      return True
+    if not any(k == _abi.FACTOR_UNIFORM_F32 for k in kinds):
+      return False
+    return float(np.float32(value)) == float(value)
 
   def close(self):
     self._engine.close()
@@ -342,7 +381,11 @@ class EnvironmentGroups(object):
 
 
 class Environment(object):
-  """Single environment with the reference's exact return types (dm_env.TimeStep of numpy)."""
+  """Single environment with the reference's exact return types (dm_env.TimeStep of numpy).
+
+  `device_reset` defaults to False here -- unlike BatchedEnvironment's 'auto' -- on purpose: the N = 1 form exists to be
+  swapped for the reference class (example_run_loop.py:62-80), and calling `init_sprites()` on the host at every reset keeps
+  the episodes those of the reference under the same np.random.seed()."""
 
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, episodes_per_pool=32, device=0,

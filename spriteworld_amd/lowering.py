@@ -193,6 +193,9 @@ class Pool(object):
     # Not consumed by the kernels; kept for SpriteFactors-style observations.
     self.angle = np.zeros((P, S), np.float64)
     self.color = np.zeros((P, S, 3), np.float64)
+    # Host-only: bit 0 / 1 set when the sprite's angle / scale is an np.float32 (factor distributions draw float32).
+    # The reference's setters take `a - self._angle` / `s - self._scale` in that type (sprite.py:163,173 under NEP 50).
+    self.attr_f32 = np.zeros((P, S), np.uint8)
 
   def assign_round_robin(self, num_envs, entries_per_env=None):
     """Env n draws entries [n*k, (n+1)*k) cyclically (k = P // num_envs)."""
@@ -270,6 +273,9 @@ def lower_episodes(episodes, task, renderers, max_sprites=None):
       theta = math.radians(sp.angle)  # matplotlib Affine2D.rotate_deg
       pool.cos_a[e, s], pool.sin_a[e, s] = math.cos(theta), math.sin(theta)
       pool.angle[e, s] = float(sp.angle)
+      # (np.float32 scalars and the 0-d float32 arrays the reference's Continuous.sample() returns alike)
+      pool.attr_f32[e, s] = ((1 if getattr(sp.angle, 'dtype', None) == np.float32 else 0) |
+                             (2 if getattr(sp.scale, 'dtype', None) == np.float32 else 0))
       pool.shape[e, s] = _shapes.shape_index(sp.shape)
       rgb = to_rgb(sp.color)
       pool.rgb[e, s, :3] = np.asarray(rgb).astype(np.uint8)

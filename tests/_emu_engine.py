@@ -164,6 +164,12 @@ class EmuEngine(object):
     check(self.lib.swb_get_state(self._h, C.byref(cs), None))
     return st
 
+  def env_state(self, env):
+    out = np.zeros(5, np.int32)
+    self.lib.swb_get_env_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    check(self.lib.swb_get_env_state(self._h, int(env), _ptr(out), None))
+    return dict(zip(('n_sprites', 'pool_entry', 'step_count', 'episode', 'reset_next'), (int(v) for v in out)))
+
   def set_positions(self, x, y):
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)

@@ -58,6 +58,10 @@ class FakeEngine(object):
   def state(self):
     return self._ora.state()
 
+  def env_state(self, env):
+    st = self._ora.state()
+    return {k: int(st[k][env]) for k in ('n_sprites', 'pool_entry', 'step_count', 'episode', 'reset_next')}
+
   def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
     try:
       self._ora.set_sprite_attr(env, sprite, attr, value, delta=delta, label=label)

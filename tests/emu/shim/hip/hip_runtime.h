@@ -160,6 +160,7 @@ inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
 // atomics: work-items are cooperative fibres of one host thread, so plain read-modify-write is atomic
 template <typename T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
 template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }

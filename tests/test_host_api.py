@@ -177,6 +177,37 @@ def test_sprite_factors_observation_and_action_noise():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('action_dtype', [np.float64, np.float32])
+def test_select_move_noise_is_gaussian_with_the_given_scale(action_dtype):
+  """action_spaces.py:69-75: `action + np.random.normal(loc=0, scale=noise_scale, size=4)`.  One big square in the middle,
+  a click on it and a fixed motion: the displacement of the sprite, divided by the motion scale, is the noise of the
+  motion component -- Kolmogorov-Smirnov against N(0, noise_scale) on 2048 environments, for float64 and float32
+  actions (numpy promotes the noised float32 action to float64: the engine then runs its float64-action arithmetic)."""
+  import scipy.stats
+  from spriteworld_amd import environment
+  sigma, scale = 0.05, 0.25
+  env = environment.BatchedEnvironment(
+      task=tasks.NoReward(), action_space=action_spaces.SelectMove(scale=scale, noise_scale=sigma),
+      renderers={'image': renderers.PILRenderer(image_size=(64, 64), anti_aliasing=1)},
+      init_sprites=lambda: [Sprite(x=0.5, y=0.5, shape='square', scale=0.6, c0=255, c1=0, c2=0)],
+      max_episode_length=1000, num_envs=2048, episodes_per_env=1, device_reset=False, action_dtype=action_dtype)
+  assert env._cfg.action_is_f32 == 0            # pylint: disable=protected-access
+  env.seed_noise(123)
+  env.reset()
+  a = np.tile(np.array([[0.5, 0.5, 0.9, 0.3]], dtype=action_dtype), (2048, 1))
+  ts = env.step(a)
+  st = env.state()
+  dx, dy = st['x'][:, 0] - 0.5, st['y'][:, 0] - 0.5
+  assert np.all(dx != 0)                         # the click (0.5 +- 0.05) never misses a square of side 0.6
+  for d, clean in ((dx, 0.9), (dy, 0.3)):
+    noise = d / scale - (np.float64(action_dtype(clean)) - 0.5)
+    assert abs(noise.mean()) < 4 * sigma / np.sqrt(2048) and abs(noise.std() / sigma - 1) < 0.08
+    assert scipy.stats.kstest(noise, 'norm', args=(0, sigma)).pvalue > 1e-3
+  assert ts.reward.dtype == __import__('torch').float64
+  env.close()
+
+
+@pytest.mark.gpu
 def test_environment_groups_equal_the_groups_stepped_alone():
   """EnvironmentGroups: per-group streams change the schedule, not the results."""
   import torch

@@ -181,3 +181,46 @@ def test_live_sprite_api_on_the_fake_engine(monkeypatch):
   from tests import _fake_engine, _setter_cases
   monkeypatch.setattr(environment._engine, 'Engine', _fake_engine.FakeEngine)
   _setter_cases.live_sprite_case()
+
+
+@needs_reference
+def test_setters_on_float32_attributes_equal_the_reference_sprite(monkeypatch):
+  """factor distributions give sprites np.float32 scales; the reference's setter then takes `s - self._scale`
+  in float32 (NEP 50), and a value assigned once keeps the type it was given.  `LiveSprite` on a BatchedEnvironment against
+  the UNMODIFIED reference Sprite, vertices bit for bit, through a chain of assignments."""
+  from spriteworld_amd import action_spaces, environment, renderers, sprite_generators, tasks
+  from spriteworld_amd import factor_distributions as distribs
+  from tests import _fake_engine
+  ref = ref_harness.load_reference()
+  monkeypatch.setattr(environment._engine, 'Engine', _fake_engine.FakeEngine)
+  np.random.seed(9)
+  factors = distribs.Product([
+      distribs.Continuous('x', 0.2, 0.8), distribs.Continuous('y', 0.2, 0.8),
+      distribs.Discrete('shape', ['square', 'triangle', 'star_5']), distribs.Continuous('scale', 0.1, 0.25),
+      distribs.Discrete('angle', [30.0]), distribs.Continuous('c0', 0., 1.), distribs.Continuous('c1', 0.5, 1.),
+      distribs.Continuous('c2', 0.9, 1.)])
+  env = environment.BatchedEnvironment(
+      task=tasks.NoReward(), action_space=action_spaces.SelectMove(scale=0.0),
+      renderers={'image': renderers.PILRenderer(image_size=(64, 64), anti_aliasing=5)},
+      init_sprites=sprite_generators.generate_sprites(factors, num_sprites=3), max_episode_length=50,
+      num_envs=4, device_reset=False)
+  env.reset()
+  differs = 0
+  for e in range(4):
+    for k in range(3):
+      sp = env.sprites(e)[k]
+      scale0 = sp.scale
+      assert float(np.float32(scale0)) == scale0                       # drawn as float32
+      pos = sp.position
+      r = ref.sprite.Sprite(x=pos[0], y=pos[1], shape=sp.shape, angle=30.0, scale=np.float32(scale0))
+      assert np.array_equal(_bits(sp.vertices), _bits(r.vertices))
+      for value in (0.3, np.float32(0.17), 0.41):                      # float32 - then a Python float - then a float32 attribute
+        differs += float(value - np.float32(r.scale) if isinstance(r.scale, np.float32) else 0.0) != float(value) - float(r.scale)
+        sp.scale = value
+        r.scale = value
+        assert np.array_equal(_bits(sp.vertices), _bits(r.vertices)), (e, k, value)
+      sp.angle = 77.5
+      r.angle = 77.5
+      assert np.array_equal(_bits(sp.vertices), _bits(r.vertices))
+  assert differs > 0        # (the float32 subtraction is not the float64 one: the test can tell them apart)
+  env.close()

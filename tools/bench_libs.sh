@@ -1,12 +1,10 @@
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/sched2
-for rep in 1 2; do
-for lib in spriteworld_amd/csrc/libswb.so $(ls spriteworld_amd/csrc/exp_*.so 2>/dev/null); do
-  for wl in "cluster_s5 5" "cluster_s5 1" "embodied_s12 5"; do
-    set -- $wl
-    echo -n "$(basename $lib) $1 aa$2: " | tee -a gpurun_out/sched2/bench.txt
-    SWB_LIBRARY=$PWD/$lib python bench.py --steps 100 --workload $1 --aa $2 --no-extra --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['value']), d['roofline']['kernel_ms'], d['env_errors'])" | tee -a gpurun_out/sched2/bench.txt
+#!/bin/bash
+# A/B of engine builds on one box, interleaved (box-to-box and run-to-run differences are of the order of the effects looked for):
+#   tools/bench_libs.sh ROUNDS "SPECS" lib1.so lib2.so ...      SPECS as for tools/r03_quick.py
+ROUNDS=$1; SPECS=$2; shift 2
+for r in $(seq 1 $ROUNDS); do
+  for lib in "$@"; do
+    echo "== $(basename $lib) round $r"
+    SWB_LIBRARY=$PWD/$lib python tools/r03_quick.py $SPECS 2>&1 | grep -v amdgpu.ids
   done
-done
 done

@@ -2,7 +2,7 @@
 """Experiment builds of the engine: a copy of spriteworld_amd/csrc with named overlays applied, compiled for gfx950 into
 spriteworld_amd/csrc/exp_NAME.so (git-ignored; travels to the GPU box; load it with SWB_LIBRARY=...).
 
-  python tools/overlay_build.py NAME overlay[:ARG] [overlay[:ARG] ...] [--emu]
+  python tools/overlay_build.py NAME [overlay[:ARG] ...] [-DMACRO=VALUE ...] [--emu]
 
 An overlay is tools/overlays/<overlay>.py with `apply(files, arg)`: `files` maps a source file name to its text and is edited
 in place through `replace_once` (every anchor must match exactly once, so an overlay that no longer fits the sources fails
@@ -63,7 +63,8 @@ def compile_copy(name, work, csrc, extra_flags=()):
 
 
 def main():
-  args = [a for a in sys.argv[1:] if not a.startswith('--')]
+  args = [a for a in sys.argv[1:] if not a.startswith('--') and not a.startswith('-D')]
+  defines = [a for a in sys.argv[1:] if a.startswith('-D')]
   name, overlays = args[0], args[1:]
   work, csrc = make_copy(name, overlays)
   if '--emu' in sys.argv:
@@ -72,7 +73,7 @@ def main():
                           '-k', 'emu', '-p', 'no:cacheprovider'], cwd=ROOT, env=env)
     if rc != 0:
       sys.exit('emulated parity FAILED')
-  print('built', compile_copy(name, work, csrc))
+  print('built', compile_copy(name, work, csrc, defines))
 
 
 if __name__ == '__main__':
