@@ -12,14 +12,18 @@ render, with actions and state resident in HBM (reference: spriteworld/environme
 Workload (BASELINE.json `metric`, configs[2]): 8192 envs x 5 sprites, SelectMove(0.25),
 Clustering reward, 64x64 PILRenderer with anti_aliasing=5 (the COBRA renderer), synthetic pools.
 
-roofline:     algorithmic bytes per launch (12 461 B/env-step) / the fused
-              kernel's mean duration measured with HIP events on the launch stream, vs 8 TB/s HBM.
-              `kernel`, `metric` and `config` are derived from what ran (swb_variant / the lowered
-              config), `traffic` and `instructions` come from the committed PMC passes of exactly
-              this build (profiles/r02_counters.json, keyed by the library's build id) or are null.
+roofline:     a step is two kernels on one stream (cover: state + geometry + coverage -> run lists; resample: run
+              lists -> frames).  `achieved` = algorithmic bytes per step (12 461 B/env-step)
+              / the mean duration of BOTH kernels together, measured with HIP events on the launch stream, vs
+              8 TB/s HBM -- the conservative reading; `kernels` gives each kernel's own duration, and for the
+              dominant one (resample, which writes the frames) the rate of its own bytes.  `kernel`, `metric`
+              and `config` are derived from what ran (swb_variant / the lowered config); `traffic` and
+              `instructions` come from the committed PMC passes of exactly this build
+              (profiles/r03_counters.json, keyed by the library's build id) or are null.
 cpu_baseline: the CPU oracle (a C port of the reference algorithm, oracle/sw_oracle.c) stepping a
-              bounded sample of the same workload on all host cores of rank 0, with the survey's
-              rate of the unmodified Python reference beside it.
+              bounded sample of the same workload on all host cores of rank 0, with the rate of the
+              UNMODIFIED reference on all cores of the build container beside it
+              (profiles/r03_reference_cpu_all_cores.json, tools/reference_cpu_baseline.py).
 """
 import argparse
 import json
@@ -49,15 +53,15 @@ def algorithmic_bytes(cfg):
 # /root/reference does not exist on the GPU box, so the same-run CPU baseline is the C port (oracle/sw_oracle.c),
 # which is 3-9x faster per core than the reference; both figures are put in the line.
 REFERENCE_RATE_PER_CORE = {'cluster_s5': 228.0, 'goal_s5': 637.0, 'embodied_s12': 156.0}
-VALU_CYCLES_PER_INST = 4.24      # profiles/r02_ubench_valu.md + SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the step kernel
+VALU_CYCLES_PER_INST = 4.24      # profiles/r02_ubench_valu.md + SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the step kernels
 
 
 def profiled_counters(workload, envs, aa, build_id):
-  """PMC figures of the committed rocprofv3 passes (profiles/r02_counters.json) for this exact build and workload.
+  """PMC figures of the committed rocprofv3 passes (profiles/r03_counters.json) for this exact build and workload.
 
   bench.py cannot collect PMC counters itself.  The file records the build id (content hash of the kernel sources)
   the passes ran on; for any other build, workload or batch the figures are stale and None is returned."""
-  path = os.path.join(ROOT, 'profiles', 'r02_counters.json')
+  path = os.path.join(ROOT, 'profiles', 'r03_counters.json')
   if not os.path.exists(path):
     return None
   with open(path) as f:
@@ -69,7 +73,9 @@ def profiled_counters(workload, envs, aa, build_id):
   return None
 
 
-def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
+def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None):
+  """One timed run.  `gate` (N > 1): called after the warm-up, returns False when another rank failed to set up -- then
+  nothing is timed and None is returned (every rank leaves together instead of hanging in the barrier)."""
   import torch
   from spriteworld_amd import engine, workloads
   cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=4, seed=seed, anti_aliasing=aa)
@@ -79,6 +85,9 @@ def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
   for i in range(warmup):
     eng.step(acts[i % N_ACTION_SETS])
   torch.cuda.synchronize(eng.device)
+  if gate is not None and not gate(None):
+    eng.close()
+    return None
   eng.timing(True)
   if barrier:
     barrier()
@@ -92,6 +101,7 @@ def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
     torch.cuda.synchronize(eng.device)
   elapsed = time.perf_counter() - t0
   kernel_ms, launches = eng.step_time_ms()
+  cover_ms, resample_ms, _ = eng.kernel_times_ms()
   eng.timing(False)
   errors = int(eng.error.max().item())
   a_bytes = algorithmic_bytes(cfg)
@@ -101,8 +111,8 @@ def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0):
                task={0: 'NoReward', 1: 'FindGoalPosition', 2: 'Clustering'}[cfg.tasks[0].kind] if not cfg.is_meta
                else 'MetaAggregated', max_episode_length=cfg.max_episode_length)
   eng.close()
-  return dict(elapsed=elapsed, kernel_ms=kernel_ms, launches=launches, a_bytes=a_bytes, errors=errors,
-              variant=variant, facts=facts)
+  return dict(elapsed=elapsed, kernel_ms=kernel_ms, cover_ms=cover_ms, resample_ms=resample_ms, launches=launches,
+              a_bytes=a_bytes, errors=errors, variant=variant, facts=facts)
 
 
 def gpu_run_groups(name, n_envs, groups, steps, warmup, aa, device):
@@ -188,6 +198,13 @@ def cpu_baseline(name, aa, budget_s=12.0):
   out = dict(value=n_envs * steps / dt, unit='env-steps/s', cores=cores, kind='port',
              sample='%d envs x %d steps of %s (AA=%d) with oracle/sw_oracle.c on %d threads, %.1f s' %
              (n_envs, steps, name, aa, cores, dt))
+  ref_path = os.path.join(ROOT, 'profiles', 'r03_reference_cpu_all_cores.json')
+  if name == WORKLOAD and aa == 5 and os.path.exists(ref_path):
+    with open(ref_path) as f:
+      ref = json.load(f)
+    out['reference_all_cores'] = {k: ref[k] for k in ('env_steps_per_s_all_cores', 'env_steps_per_s_per_core', 'processes', 'cpu',
+                                                       'where', 'envs', 'timed_steps_per_env')}
+    out['reference_all_cores']['source'] = 'profiles/r03_reference_cpu_all_cores.json (tools/reference_cpu_baseline.py)'
   if name in REFERENCE_RATE_PER_CORE and aa == 5:
     out['reference_env_steps_per_s_per_core'] = REFERENCE_RATE_PER_CORE[name]
     out['reference_note'] = ('the unmodified Python reference measured %.0f env-steps/s on one core for this config '
@@ -201,28 +218,50 @@ def assemble_line(args, res, elapsed):
   `elapsed` the max-over-ranks wall time of the timed region.  Pure host code (tests call it without a GPU)."""
   total_envs = args.envs_per_gpu * args.gpus
   value = total_envs * args.steps / elapsed
-  kernel_s = res['kernel_ms'] / 1e3 / max(res['launches'], 1)
+  n_launch = max(res['launches'], 1)
+  kernel_s = res['kernel_ms'] / 1e3 / n_launch                       # both kernels of a step, HIP events on the launch stream
+  cover_s, resample_s = res.get('cover_ms', 0.0) / 1e3 / n_launch, res.get('resample_ms', 0.0) / 1e3 / n_launch
   achieved = res['a_bytes'] * args.envs_per_gpu / kernel_s / 1e9
   facts, variant = res['facts'], res['variant']
   image = '%dx%d' % (facts['image'][1], facts['image'][0])
+  obs_bytes = 3 * facts['image'][0] * facts['image'][1]
   counters = profiled_counters(args.workload, args.envs_per_gpu, args.aa, variant['build_id'])
+  second = variant['kernel']
+  first = variant.get('cover_kernel', 'swb_cover_kernel')
   roofline = {
       'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
       'frac': achieved / HBM_PEAK_GBS, 'frac_of_measured_copy_peak': achieved / 6290.0,
       'traffic': counters['hbm_traffic_bytes_per_launch'] if counters else None,
-      'kernel': variant['kernel'], 'kernel_ms': kernel_s * 1e3,
+      'kernel': '%s + %s' % (first, second), 'kernel_ms': kernel_s * 1e3,
       'algorithmic_bytes_per_env_step': res['a_bytes'],
+      # each kernel on its own: the second one writes the frames (98.6 % of the algorithmic bytes)
+      'kernels': [
+          {'name': first, 'ms': cover_s * 1e3, 'waves_per_simd': variant['waves_per_simd'],
+           'lds_bytes_per_wave': variant['lds_bytes_per_wave']},
+          {'name': second, 'ms': resample_s * 1e3, 'waves_per_simd': variant.get('resample_waves_per_simd'),
+           'bands': variant.get('n_bands'), 'column_groups': variant.get('n_column_groups'),
+           'achieved_GBs_frames_only': (obs_bytes * args.envs_per_gpu / resample_s / 1e9) if resample_s > 0 else None,
+           'frac_frames_only': (obs_bytes * args.envs_per_gpu / resample_s / 1e9 / HBM_PEAK_GBS) if resample_s > 0 else None},
+      ],
       'lds_bytes_per_wave': variant['lds_bytes_per_wave'], 'waves_per_simd': variant['waves_per_simd'],
       'build_id': variant['build_id'],
   }
   if counters:
-    # instruction side (SURVEY 8d asks for both): the kernel is bound by instruction issue, not by HBM
-    waves_per_simd_resident = counters.get('resident_waves_per_simd', variant['waves_per_simd'])
+    # instruction side (SURVEY 8d asks for both): the step is bound by instruction issue, not by HBM.  Per environment:
+    # what the two kernels retire, the time that alone takes on a SIMD's vector ALU, and the cost model's minimum for
+    # the resample kernel from exact event counts (tools/r03_assemble.py, tools/emu_stats.py)
+    valu = counters['insts_valu_per_env']
+    envs_per_simd = args.envs_per_gpu / 1024.0
     roofline['instructions'] = {
-        'insts_valu_per_wave': counters['insts_valu_per_wave'], 'insts_salu_per_wave': counters['insts_salu_per_wave'],
-        'insts_lds_per_wave': counters['insts_lds_per_wave'],
+        'insts_valu_per_env': valu, 'insts_salu_per_env': counters['insts_salu_per_env'],
+        'insts_valu_per_env_by_kernel': counters['insts_valu_per_env_by_kernel'],
         'valu_cycles_per_inst': VALU_CYCLES_PER_INST,
-        'valu_issue_frac': counters['active_inst_valu_per_wave'] * waves_per_simd_resident / counters['wave_cycles_per_wave'],
+        'valu_issue_ms_per_step': valu * envs_per_simd * VALU_CYCLES_PER_INST / 2.4e9 * 1e3,
+        'valu_issue_frac_of_step': valu * envs_per_simd * VALU_CYCLES_PER_INST / 2.4e9 / kernel_s,
+        'resample_valu_model_min_per_env': counters.get('resample_valu_model_min_per_env'),
+        'resample_valu_measured_over_model': (counters['insts_valu_per_env_by_kernel'].get('resample', 0) /
+                                               counters['resample_valu_model_min_per_env'])
+        if counters.get('resample_valu_model_min_per_env') else None,
         'source': counters['source'],
     }
   else:
@@ -296,18 +335,49 @@ def main():
     barrier = dist.barrier
   device = local_rank if dist is not None else 0
 
-  res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
-                barrier=barrier, seed=rank)
-  elapsed = res['elapsed']
-  if dist is not None:
+  # N > 1: every rank reports whether it got as far as the timed region before any rank enters it, so that rank 0 prints
+  # its line (with the failing ranks' errors) whatever happens on the others
+  setup_errors = []
+
+  def gate(error):
+    if dist is None:
+      return error is None
+    status = [None] * world
+    dist.all_gather_object(status, error)
+    setup_errors[:] = [(r, e) for r, e in enumerate(status) if e is not None]
+    return not setup_errors
+
+  res = None
+  try:
+    res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
+                  barrier=barrier, seed=rank, gate=gate if dist is not None else None)
+  except Exception as e:  # pylint: disable=broad-except
+    if dist is None:
+      raise
+    if not setup_errors:                    # failed before the gate: tell the others (they are waiting in it)
+      gate('rank %d: %r' % (rank, e))
+    else:
+      setup_errors.append((rank, repr(e)))
+  per_rank = None
+  elapsed = res['elapsed'] if res else None
+  if dist is not None and res is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else 'cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    per_rank = [None] * world
+    n_l = max(res['launches'], 1)
+    dist.all_gather_object(per_rank, {'rank': rank, 'device': torch.cuda.get_device_name(device), 'local_device': device,
+                                      'elapsed_s': res['elapsed'], 'kernel_ms': res['kernel_ms'] / n_l,
+                                      'cover_ms': res['cover_ms'] / n_l, 'resample_ms': res['resample_ms'] / n_l,
+                                      'env_errors': res['errors']})
 
   gather = None
-  if args.gather_obs and dist is not None:
+  if args.gather_obs and dist is not None and res is not None:
     from spriteworld_amd import distributed as swd
-    gather = swd.bench_allgather(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device, rank)
+    # both schedules of the gather (distributed.py): 'ring' = all_gather_into_tensor, 'direct' = point-to-point copies to
+    # every peer at once (all seven xGMI links of a GPU busy); step_ms and gather_ms apart, HIP events per step
+    gather = {m: swd.bench_allgather(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device, rank, method=m)
+              for m in ('ring', 'direct')}
 
   if rank != 0:
     if dist is not None:
@@ -315,7 +385,22 @@ def main():
       dist.destroy_process_group()
     return
 
+  if res is None:                            # some rank could not set up: still ONE line from rank 0
+    print(json.dumps({'metric': 'env-steps/sec (incl. RGB render) at %d envs' % args.envs_per_gpu, 'value': None,
+                      'unit': 'env-steps/s', 'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup,
+                      'world_size': world, 'backend': dist.get_backend() if dist is not None else None,
+                      'rank_errors': [{'rank': r, 'error': e} for r, e in setup_errors]}))
+    if dist is not None:
+      dist.barrier()
+      dist.destroy_process_group()
+    return
+
   out = assemble_line(args, res, elapsed)
+  if dist is not None:
+    # what torch.distributed itself saw (the driver can check that RCCL really ran N ranks) and every rank's own kernel time
+    out['world_size'] = dist.get_world_size()
+    out['backend'] = dist.get_backend()
+    out['per_rank'] = per_rank
   if gather is not None:
     out['obs_allgather'] = gather
   if args.gpus == 1 and not args.no_extra:
@@ -332,6 +417,7 @@ def main():
       r = gpu_run(nm, n, short, 5, aa, device)
       ks = r['kernel_ms'] / 1e3 / max(r['launches'], 1)
       extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel': r['variant']['kernel'], 'kernel_ms': ks * 1e3,
+                      'cover_ms': r['cover_ms'] / max(r['launches'], 1), 'resample_ms': r['resample_ms'] / max(r['launches'], 1),
                       'hbm_GBs': r['a_bytes'] * n / ks / 1e9, 'hbm_frac': r['a_bytes'] * n / ks / 1e9 / HBM_PEAK_GBS,
                       'env_errors': r['errors']}
     # the headline batch as two groups of 4096 on two HIP streams: consecutive steps of different groups overlap,

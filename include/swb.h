@@ -127,6 +127,11 @@ typedef struct swb_config {
  *   rgb         = renderer _color_to_rgb(sprite.color)  (pil_renderer.py:82)
  *   label[t]    = FindGoal: filter_distrib.contains(factors) (tasks.py:134-137)
  *                 Clustering: first matching cluster index or -1 (tasks.py:196-205)
+ *                 NOT SUPPORTED: filters keyed on x / y (or x_vel / y_vel).  The reference evaluates contains() at
+ *                 every step; here membership is a label fixed per episode (re-evaluated only by swb_set_sprite_attr),
+ *                 which is exact for every factor that cannot change inside an episode and wrong for position.
+ *                 The Python lowering refuses such tasks (lowering.LoweringError); a C caller must do the same.
+ *                 No shipped reference config filters on position.
  * Environment n draws entries pool_base[n] + (k mod pool_len[n]), k = 0,1,2...
  */
 typedef struct swb_pool {
@@ -331,9 +336,10 @@ int swb_get_sprite(swb_handle h, int32_t env, int32_t sprite, int32_t* shape, do
  *   SWB_ATTR_SCALE  out = Affine2D().scale(a - b).transform_path(in) */
 int swb_sprite_path_op(int32_t attr, double a, double b, int32_t n, const double* in_xy, double* out_xy);
 
-/* Which build of the fused step kernel swb_step launches for this handle -- the template parameters
- * of swb_step_kernel<NW, NCOL, VS> (32-pixel canvas words per row, output columns per lane, output
- * rows in flight in the vertical pass) and its LDS footprint -- so that measurement code labels a
+/* Which kernels swb_step launches for this handle -- a step is two kernels on the caller's stream: "cover" (state,
+ * geometry, coverage -> run lists; swb_cover_kernel<NW>, NW = 32-pixel canvas words per row, one wave per environment)
+ * and "resample" (swb_resample_kernel<VS>, VS output rows in flight; swb_fill_kernel when anti_aliasing = 1), one wave
+ * per (environment, group of 64 output columns, band of output rows) -- so that measurement code can label a
  * run by what actually ran.  swb_build_id(): content hash of the sources and flags the library was
  * built from (spriteworld_amd/build.py), "unknown" for a hand build. */
 typedef struct swb_variant_info {

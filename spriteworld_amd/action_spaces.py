@@ -3,7 +3,7 @@
 Mirrors of the reference constructors and attribute names (reference:
 spriteworld/action_spaces.py:29-111 SelectMove, :114-137 DragAndDrop, :140-221
 Embodied).  `step()` is not implemented on the host: applying an action is part
-of the fused HIP step kernel; these objects only describe *which* action space
+of the HIP cover kernel; these objects only describe *which* action space
 the batch uses (`lowering.lower_config` reads `_scale`, `_motion_cost`,
 `_noise_scale`, `_step_size`, exactly the attributes the reference sets) and
 provide `sample()` / `action_spec()`.

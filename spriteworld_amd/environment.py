@@ -54,7 +54,7 @@ class EnvironmentError_(RuntimeError):
 
 
 class BatchedEnvironment(object):
-  """N independent Spriteworld environments stepped by one fused HIP kernel."""
+  """N independent Spriteworld environments stepped by the HIP engine (two kernels per step, csrc/swb_kernels.hip.inc)."""
 
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, num_envs=1, episodes_per_env=8,

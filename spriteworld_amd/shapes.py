@@ -5,9 +5,9 @@ spriteworld/shapes.py:34-116 `polygon`, `star`, `spokes`;
 spriteworld/constants.py:27-56 `SHAPES`, `ShapeType`).  The tables are uploaded
 to the GPU once (`swb_upload_shapes`) and every vertex the kernels touch is
 derived from them in float64, so the values have to be bit-identical to the
-reference's: tests/test_shapes.py checks that against the committed golden
-table (tests/golden/shapes.json) and, when the reference tree is present,
-against `spriteworld.constants.SHAPES` itself.
+reference's: tests/test_golden.py::test_shape_tables_match_reference_values checks
+that against the committed golden table (tests/golden/shapes.json) and, when the
+reference tree is present, against `spriteworld.constants.SHAPES` itself.
 """
 import enum
 

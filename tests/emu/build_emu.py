@@ -47,8 +47,8 @@ def _rewrite(text, name):
 
 # SWB_EMU_STATS=1: event counters at a few anchor points of the kernel source (counted by lane 0 of each wave), read back
 # through emu_stats() -- exact dynamic figures for the cost model in DESIGN.md (tools/emu_stats.py).
-_COUNTERS = ('p3_row_runs', 'p3_rows_in_runs', 'p3_spans', 'p3_nonempty_rows', 'p3_completed_rows', 'p2_batches',
-             'p2_sprite_passes', 'p2_edge_iterations', 'p2_transition_steps')
+_COUNTERS = ('p3_row_runs', 'p3_rows_in_runs', 'p3_spans', 'p3_completed_rows', 'p3_clean_rows', 'p2_batches',
+             'p2_sprite_passes', 'p2_edge_iterations', 'p2_transition_steps', 'run_units')
 
 
 def _instrument(text):
@@ -61,17 +61,17 @@ def _instrument(text):
     text = text.replace(anchor, anchor + code)
 
   text = text.replace('#define SWB_WAVE 64', '#define SWB_WAVE 64\nextern "C" void emu_count(int counter, long amount);', 1)
-  after('          const int r = __builtin_ctzll(mask);', hook('p3_row_runs'))
-  after('            const int e = __builtin_ctzll(ends);', hook('p3_rows_in_runs', '__builtin_popcountll(mask & (~0ull >> (63 - e)))'))
-  after('          first_span(sp0, h);', hook('p3_spans'))
-  after('            add_span((uint32_t)__builtin_amdgcn_readlane((int)rs.s1, r), h);', hook('p3_spans'))
-  after('              add_span((uint32_t)__builtin_amdgcn_readlane((int)rs.s2, r), h);', hook('p3_spans') + hook('p3_spans', 'ns - 3'))
-  after('      unsigned long long todo = (p.bg == 0u) ? __ballot(rs.cnt != 0u) : ~0ull;', hook('p3_nonempty_rows', '__builtin_popcountll(todo & (rows < 64 ? (1ull << rows) - 1ull : ~0ull))'))
-  after('    auto complete_row = [&]() __attribute__((always_inline)) {', hook('p3_completed_rows'))
+  # resample kernel: runs, the canvas rows they stand for, their spans; finished output rows and the untouched ones
+  after('      while ((int)(rec.x & 0xffffu) <= next_end) {',
+        hook('p3_row_runs') + hook('p3_rows_in_runs', '(long)((rec.x >> 16) & 63u) + 1') + hook('p3_spans', '(long)std::max(1u, rec.x >> 24)'))
+  after('      // finish output row r_first: clip, pack, store; rows above the band only free their slot\n', '     ' + hook('p3_completed_rows') + '\n')
+  after('      if (black && mark[k] == uo) {', hook('p3_clean_rows'))
+  # cover kernel: coverage passes and what they emit
   after('    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)sp_a, s);', hook('p2_sprite_passes'))
   after('  rs.cnt = 0; rs.s0 = rs.s1 = rs.s2 = 0u;', hook('p2_batches'))
   after('        for (int e = 0; e < ne; ++e) {', hook('p2_edge_iterations'))
   after('        for (int j = 0; j < bound; j += (1 << lg)) {', hook('p2_edge_iterations'))
+  after('    const int total = __builtin_amdgcn_readlane(incl, SWB_WAVE - 1);', hook('run_units', 'total'))
   anchor = '        auto take = [&]() __attribute__((always_inline)) {'
   assert text.count(anchor) == 1, anchor
   text = text.replace(anchor, anchor + hook('p2_transition_steps') + ' ')

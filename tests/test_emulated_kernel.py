@@ -89,6 +89,44 @@ def test_emulated_kernel_span_overflow_slots(monkeypatch, name, n_envs, aa):
   _run(name, n_envs, 3, aa)
 
 
+# ---- the hand-off between the two kernels of a step (round 3): bands of output rows, cost-ordered dispatch, list capacity
+@pytest.mark.parametrize('bands', [1, 2, 3, 8])
+@pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 3, 5), ('embodied_s12', 2, 5), ('geom_100x60', 2, 3), ('geom_64x256', 2, 1),
+                                            ('geom_96x48', 2, 3), ('cluster_s5', 3, 1)])
+def test_emulated_kernel_any_number_of_bands(monkeypatch, bands, name, n_envs, aa):
+  """The resample / fill kernel splits an image into bands of output rows (one wave each); a band starts with the output rows
+  already in flight at its first canvas row.  Every band count gives the same frames."""
+  monkeypatch.setenv('SWB_BANDS', str(bands))
+  _run(name, n_envs, 3, aa)
+
+
+def test_emulated_kernel_without_cost_ordered_dispatch(monkeypatch):
+  monkeypatch.setenv('SWB_NO_COST_ORDER', '1')
+  _run('cluster_s5', 11, 4, 5)
+  _run('cluster_s5', 11, 3, 1)
+
+
+@pytest.mark.parametrize('name,aa', [('cluster_s5', 5), ('cluster_s5', 1)])
+def test_emulated_kernel_cost_order_covers_every_environment(name, aa):
+  """Sizes that do not divide by the eight shards or the four waves of a resample block."""
+  for n in (1, 7, 9, 33):
+    _run(name, n, 3, aa)
+
+
+def test_emulated_kernel_run_list_overflow_is_flagged(monkeypatch):
+  """A run list that does not fit its capacity (swb_params::run_cap; SWB_RUN_CAP lowers it) flags the environment
+  (SWB_ENV_ERR_SPAN_OVERFLOW) instead of writing past it."""
+  from spriteworld_amd import _abi
+  monkeypatch.setenv('SWB_RUN_CAP', '24')
+  cfg, pool, sample = workloads.build('cluster_s5', 4, episodes_per_env=2, seed=0, anti_aliasing=5)
+  eng = _emu(cfg, pool)
+  rng = np.random.default_rng(0)
+  eng.step(sample(rng))
+  got = eng.outputs_host()
+  assert (got['error'] & _abi.ENV_ERR_SPAN_OVERFLOW).all()
+  eng.close()
+
+
 @pytest.mark.parametrize('name', _util.golden_cases())
 def test_emulated_kernel_reproduces_the_reference_fixtures(name):
   """tests/golden/*.npz (outputs recorded from the unmodified reference): the first 50 steps of every fixture."""

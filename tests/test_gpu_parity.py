@@ -136,3 +136,35 @@ def test_image_geometries(geom, aa):
 def test_randomised_configurations(seed):
   """Seeded random configurations: geometry x anti-aliasing x sprite counts x shapes x task x action space x dtype."""
   _run('fuzz_%d' % seed, 64, 10, 5, seed=seed)
+
+
+# ---- the hand-off between the two kernels of a step (round 3)
+@pytest.mark.parametrize('bands', [1, 2, 4, 8])
+@pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 64, 5), ('embodied_s12', 32, 5), ('geom_100x60', 32, 3), ('geom_64x256', 32, 1),
+                                            ('cluster_s5', 64, 1)])
+def test_any_number_of_bands(monkeypatch, bands, name, n_envs, aa):
+  """Bands of output rows (one wave of the resample / fill kernel each; small batches use several): same frames."""
+  monkeypatch.setenv('SWB_BANDS', str(bands))
+  _run(name, n_envs, 3, aa)
+
+
+@pytest.mark.parametrize('n_envs', [1, 7, 9, 33, 1000])
+def test_cost_ordered_dispatch_covers_every_environment(n_envs):
+  """Batch sizes that do not divide by the eight shards of the cost buckets or the four waves of a resample block."""
+  _run('cluster_s5', n_envs, 3, 5)
+  _run('cluster_s5', n_envs, 2, 1)
+
+
+def test_without_cost_ordered_dispatch(monkeypatch):
+  monkeypatch.setenv('SWB_NO_COST_ORDER', '1')
+  _run('cluster_s5', 100, 4, 5)
+
+
+def test_run_list_overflow_is_flagged(monkeypatch):
+  from spriteworld_amd import _abi, engine
+  monkeypatch.setenv('SWB_RUN_CAP', '24')
+  cfg, pool, sample = workloads.build('cluster_s5', 64, episodes_per_env=2, seed=0, anti_aliasing=5)
+  eng = engine.Engine(cfg, pool)
+  eng.step(sample(np.random.default_rng(0)))
+  assert (eng.outputs_host()['error'] & _abi.ENV_ERR_SPAN_OVERFLOW).all()
+  eng.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""ISA resource table of every swb_step_kernel variant of the shipped sources: compiles both translation units with the
+"""ISA resource table of every kernel of the shipped sources (cover, resample, fill, factors, sampler): compiles both translation units with the
 flags of spriteworld_amd/build.py plus -save-temps (in a temporary directory) and reads the kernel descriptors' metadata.
 usage: python tools/isa_resources.py [CSRC_DIR] > table.md"""
 import os
@@ -20,10 +20,17 @@ def kernels_of(asm):
   for block in meta.split('  - .agpr_count:')[1:]:
     block = '  - .agpr_count:' + block
     name = re.search(r'\.name:\s+(\S+)', block).group(1)
-    if 'swb_step_kernel' not in name:
+    if 'swb_' not in name:
       continue
-    m = re.search(r'swb_step_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])E', name)
-    key = '<%s,%s,%s%s>' % (m.group(1), m.group(2), m.group(3), ',OV' if m.group(4) == '1' else '')
+    m = re.search(r'swb_cover_kernelILi(\d+)ELb([01])E', name)
+    if m:
+      key = 'swb_cover_kernel<%s%s>' % (m.group(1), ',OV' if m.group(2) == '1' else '')
+    else:
+      m = re.search(r'swb_resample_kernelILi(\d+)E', name)
+      key = 'swb_resample_kernel<%s>' % m.group(1) if m else re.sub(r'^_Z\d+', '', name).split('1')[0] if False else None
+      if key is None:
+        m = re.search(r'_Z\d+(swb_\w+?_kernel)', name)
+        key = m.group(1) if m else name
     f = lambda k: int(re.search(r'\.%s:\s+(\d+)' % k, block).group(1))
     out[key] = dict(vgpr=f('vgpr_count'), agpr=f('agpr_count'), sgpr=f('sgpr_count'), vspill=f('vgpr_spill_count'),
                     sspill=f('sgpr_spill_count'), scratch=f('private_segment_fixed_size'))
@@ -43,9 +50,9 @@ def main():
         rows.append((unit, key, r))
   def order(row):
     nums = [int(v) for v in re.findall(r'\d+', row[1])]
-    return (nums, 'OV' in row[1])
+    return (row[1].split('<')[0], nums, 'OV' in row[1])
   rows.sort(key=order)
-  print('| variant | translation unit | VGPRs | AGPRs | SGPRs | VGPR spills | SGPR spills | scratch B/lane | waves/SIMD by registers |')
+  print('| kernel | translation unit | VGPRs | AGPRs | SGPRs | VGPR spills | SGPR spills | scratch B/lane | waves/SIMD by registers |')
   print('|---|---|---|---|---|---|---|---|---|')
   for unit, key, r in rows:
     alloc = (r['vgpr'] + r['agpr'] + 7) // 8 * 8
