@@ -58,18 +58,18 @@ def main():
     if by:
       lines += ['', '## Counters per kernel (rocprofv3 --pmc, one process per counter set, tools/r03_pmc.sh; averages per dispatch, '
                 'per environment where divided)', '',
-                '| kernel | waves | VALU / env | SALU / env | LDS / env | SMEM / env | wave quad-cycles / wave | VALU-active x resident waves / wave cycles | '
-                'WRITE_SIZE MB | 2 x FETCH_SIZE MB |', '|---|---|---|---|---|---|---|---|---|---|']
+                '| kernel | waves | VALU / env | SALU / env | LDS / env | SMEM / env | wave quad-cycles / wave | vector ALU busy (SQ_ACTIVE_INST_VALU x 4 cycles '
+                '/ 1024 SIMDs / 2.4 GHz / kernel time) | WRITE_SIZE MB | 2 x FETCH_SIZE MB |', '|---|---|---|---|---|---|---|---|---|---|']
+      kms = {('cover' if 'cover' in k['name'] else 'resample'): k['ms'] for k in bench['roofline']['kernels']}
       for role in ('cover', 'resample'):
         c = by.get(role)
         if not c:
           continue
         waves = c.get('SQ_WAVES', envs)
-        res_waves = 5 if role == 'cover' else 8
         lines.append('| `%s` | %d | %.0f | %.0f | %.0f | %.0f | %.0f | %.2f | %.1f | %.1f |' % (
             c['kernel'], waves, c.get('SQ_INSTS_VALU', 0) / envs, c.get('SQ_INSTS_SALU', 0) / envs, c.get('SQ_INSTS_LDS', 0) / envs,
             c.get('SQ_INSTS_SMEM', 0) / envs, c.get('SQ_WAVE_CYCLES', 0) / max(waves, 1),
-            c.get('SQ_ACTIVE_INST_VALU', 0) * res_waves / max(c.get('SQ_WAVE_CYCLES', 1), 1),
+            c.get('SQ_ACTIVE_INST_VALU', 0) * 4.0 / 1024.0 / 2.4e9 / max(kms.get(role, 0.0) * 1e-3, 1e-12),
             c.get('WRITE_SIZE', 0) / 1024.0, 2 * c.get('FETCH_SIZE', 0) / 1024.0))
     a_bytes = bench['roofline']['algorithmic_bytes_per_env_step'] * envs
     traffic = sum((c.get('WRITE_SIZE', 0) + 2.0 * c.get('FETCH_SIZE', 0)) * 1024 for c in by.values())
@@ -94,8 +94,11 @@ def main():
     if by:
       records.append(rec)
       if have_traffic:
-        lines += ['', 'HBM traffic per step = WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction) over both kernels = %.1f MB; algorithmic bytes = %.1f MB '
-                  '(x %.2f).' % (traffic / 1e6, a_bytes / 1e6, traffic / a_bytes)]
+        raw = sum((c.get('WRITE_SIZE', 0) + c.get('FETCH_SIZE', 0)) * 1024 for c in by.values())
+        lines += ['', 'HBM traffic per step = WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md, calibrated there on wide streaming reads) over '
+                  'both kernels = %.1f MB; algorithmic bytes = %.1f MB (x %.2f).  Uncorrected (WRITE_SIZE + FETCH_SIZE): %.1f MB (x %.2f) -- the reads here are scalar '
+                  'loads and 4-8-byte vector loads, whose FETCH_SIZE about equals the bytes the kernels ask for (the run lists and headers the cover kernel '
+                  'writes and the resample kernel reads: 1.6 KB per environment on the headline scene).' % (traffic / 1e6, a_bytes / 1e6, traffic / a_bytes, raw / 1e6, raw / a_bytes)]
       if model:
         lines += ['', 'Resample kernel, vector instructions per environment: measured %.0f, cost-model minimum %.0f (x %.2f; tools/emu_stats.py).' % (
             rec['insts_valu_per_env_by_kernel'].get('resample', 0), model, rec['insts_valu_per_env_by_kernel'].get('resample', 0) / model)]
