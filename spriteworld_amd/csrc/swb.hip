@@ -121,7 +121,7 @@ struct variant { int nw; kernel_fn fn, fn_ov; size_t lds_fixed, outrow_bytes; };
 
 template <int NW>
 variant make_variant() {
-  const size_t outrow = 392;          // wave_lds::outrow is build_all_edges' scratch (98 dwords)
+  const size_t outrow = 528;          // wave_lds::outrow is build_all_edges' scratch (132 dwords)
   return {NW, swb_cover_kernel<NW>, swb_cover_kernel<NW, true>, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
 }
 
