@@ -232,7 +232,8 @@ def assemble_line(args, res, elapsed):
       'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
       'frac': achieved / HBM_PEAK_GBS, 'frac_of_measured_copy_peak': achieved / 6290.0,
       'traffic': counters['hbm_traffic_bytes_per_launch'] if counters else None,
-      'kernel': '%s + %s' % (first, second), 'kernel_ms': kernel_s * 1e3,
+      'kernel': ('%s + %s' % (first, second)) if not second.startswith('none') else first + ' (paints the frame: anti_aliasing = 1)',
+      'kernel_ms': kernel_s * 1e3,
       'algorithmic_bytes_per_env_step': res['a_bytes'],
       # each kernel on its own: the second one writes the frames (98.6 % of the algorithmic bytes)
       'kernels': [
@@ -246,6 +247,9 @@ def assemble_line(args, res, elapsed):
       'lds_bytes_per_wave': variant['lds_bytes_per_wave'], 'waves_per_simd': variant['waves_per_simd'],
       'build_id': variant['build_id'],
   }
+  if second.startswith('none'):
+    roofline['kernels'] = roofline['kernels'][:1]
+    roofline['kernels'][0]['ms'] = kernel_s * 1e3
   if counters:
     # instruction side (SURVEY 8d asks for both): the step is bound by instruction issue, not by HBM.  Per environment:
     # what the two kernels retire, the time that alone takes on a SIMD's vector ALU, and the cost model's minimum for

@@ -352,6 +352,8 @@ typedef struct swb_variant_info {
   int32_t n_bands;            /* bands of output rows: waves of the second kernel per (environment, column group) */
   int32_t n_column_groups;    /* groups of 64 output columns */
   int32_t run_cap;            /* capacity of a run list (8-byte units per environment and column group) */
+  int32_t paint_in_cover;     /* 1: anti_aliasing = 1 and an image of up to 64 columns -- the cover kernel writes the frame
+                               * itself and no second kernel is launched */
 } swb_variant_info;
 int swb_variant(swb_handle h, swb_variant_info* out);
 const char* swb_build_id(void);

@@ -309,6 +309,8 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   }
   const size_t lds2 = p.AA == 1 ? 0 : (((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15);
   p.parity = h->launch_parity;
+  // anti_aliasing = 1, one column group: the cover kernel paints the frame itself, there is no second kernel
+  p.paint_in_cover = (p.AA == 1 && p.ncg == 1 && p.obs && !getenv("SWB_NO_PAINT_IN_COVER")) ? 1 : 0;
   // (cost-ordered: block b serves rank b / 8 of shard b % 8; a shard holds up to cost_cap environments)
   auto launch_cover = [&](int e0, int e1) {
     hipLaunchKernelGGL(fn, dim3(e1 - e0), dim3(SWB_WAVE), lds, stream, p);
@@ -321,14 +323,15 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   };
   launch_cover(0, c.n_envs);
   HIP_TRY(hipGetLastError());
-  if (h->timing) HIP_TRY(hipEventRecord(ev.e1, stream));
-  if (p.obs) launch_resample(0, c.n_envs, stream);
+  if (h->timing && !p.paint_in_cover) HIP_TRY(hipEventRecord(ev.e1, stream));
+  if (p.obs && !p.paint_in_cover) launch_resample(0, c.n_envs, stream);
   HIP_TRY(hipGetLastError());
   if (!p.obs && p.cost_cnt)       // no second kernel to clear the next launch's bucket counters
     HIP_TRY(hipMemsetAsync(h->d_cost_cnt + (size_t)(p.parity ^ 1) * SWB_COST_SHARDS * SWB_COST_BUCKETS, 0,
                            SWB_COST_SHARDS * SWB_COST_BUCKETS * sizeof(uint32_t), stream));
   h->launch_parity ^= 1;
   if (h->timing) {
+    if (p.paint_in_cover) HIP_TRY(hipEventRecord(ev.e1, stream));      // (no second kernel: the whole step is the cover kernel)
     HIP_TRY(hipEventRecord(ev.e2, stream));
     h->events.push_back(ev);
     if (h->events.size() >= 4096) return flush_timing(h);
@@ -1072,6 +1075,7 @@ int swb_variant(swb_handle h, swb_variant_info* out) {
   out->n_bands = h->p.nbands ? h->p.nbands : h->nbands;
   out->n_column_groups = (h->p.Wo + 63) / 64;
   out->run_cap = h->p.run_cap;
+  out->paint_in_cover = (h->p.AA == 1 && (h->p.Wo + 63) / 64 == 1 && !getenv("SWB_NO_PAINT_IN_COVER")) ? 1 : 0;
   return SWB_OK;
 }
 

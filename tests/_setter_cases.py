@@ -63,7 +63,7 @@ def run_parity(make_engine, name, n_envs, steps, aa, seed=0, calls_per_step=6):
     if t % 3 == 0:
       np.testing.assert_array_equal(eng.render().cpu().numpy(), ora.render(), err_msg='render t=%d' % t)
   assert applied > 0
-  assert eng.variant()['kernel'].startswith(('swb_resample_kernel', 'swb_fill_kernel'))
+  assert eng.variant()['kernel'].startswith(('swb_resample_kernel', 'swb_fill_kernel', 'none'))
   eng.close()
 
 

@@ -113,6 +113,14 @@ def test_emulated_kernel_cost_order_covers_every_environment(name, aa):
     _run(name, n, 3, aa)
 
 
+@pytest.mark.parametrize('name,n_envs', [('cluster_s5', 3), ('tiny_s6', 4), ('wide_s4', 2), ('ragged_s16', 8)])
+def test_emulated_fill_kernel_for_narrow_images(monkeypatch, name, n_envs):
+  """anti_aliasing = 1: images of up to 64 columns are painted by the cover kernel itself (the default, in every other AA = 1
+  case of this file); SWB_NO_PAINT_IN_COVER sends them through the run lists and the fill kernel like wider images."""
+  monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')
+  _run(name, n_envs, 3, 1)
+
+
 def test_emulated_kernel_run_list_overflow_is_flagged(monkeypatch):
   """A run list that does not fit its capacity (swb_params::run_cap; SWB_RUN_CAP lowers it) flags the environment
   (SWB_ENV_ERR_SPAN_OVERFLOW) instead of writing past it."""

@@ -168,3 +168,11 @@ def test_run_list_overflow_is_flagged(monkeypatch):
   eng.step(sample(np.random.default_rng(0)))
   assert (eng.outputs_host()['error'] & _abi.ENV_ERR_SPAN_OVERFLOW).all()
   eng.close()
+
+
+@pytest.mark.parametrize('name,n_envs', [('cluster_s5', 64), ('tiny_s6', 48), ('wide_s4', 32), ('ragged_s16', 96)])
+def test_fill_kernel_for_narrow_images(monkeypatch, name, n_envs):
+  """anti_aliasing = 1: images of up to 64 columns are painted by the cover kernel itself; SWB_NO_PAINT_IN_COVER sends them
+  through the run lists and the fill kernel, the path wider images always take (test_image_geometries covers those)."""
+  monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')
+  _run(name, n_envs, 3, 1)

@@ -11,4 +11,4 @@ def apply(files, arg, replace_once):
   replace_once(files, 'swb_kernels.hip.inc', '#ifndef SWB_HOOK_PHASE_END\n#define SWB_HOOK_PHASE_END(k)\n#endif\n',
                '#define SWB_HOOK_PHASE_END(k) { if ((k) == %d) { if (lane_id() == 0) ovf_slot_release(p, ovf); return; } }\n' % cut)
   # no run lists are written: the second kernel must not run
-  replace_once(files, 'swb.hip', '  if (p.obs) launch_resample(0, c.n_envs, stream);\n', '  (void)launch_resample;\n')
+  replace_once(files, 'swb.hip', '  if (p.obs && !p.paint_in_cover) launch_resample(0, c.n_envs, stream);\n', '  (void)launch_resample;\n')

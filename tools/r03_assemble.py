@@ -73,7 +73,7 @@ def main():
             c.get('WRITE_SIZE', 0) / 1024.0, 2 * c.get('FETCH_SIZE', 0) / 1024.0))
     a_bytes = bench['roofline']['algorithmic_bytes_per_env_step'] * envs
     traffic = sum((c.get('WRITE_SIZE', 0) + 2.0 * c.get('FETCH_SIZE', 0)) * 1024 for c in by.values())
-    have_traffic = all('WRITE_SIZE' in c and 'FETCH_SIZE' in c for c in by.values()) and len(by) == 2
+    have_traffic = all('WRITE_SIZE' in c and 'FETCH_SIZE' in c for c in by.values()) and len(by) == (1 if 'paints the frame' in bench['roofline']['kernel'] else 2)
     model, events = model_min(workload, aa)
     rec = {
         'build_id': bench['roofline']['build_id'], 'workload': workload, 'envs': envs, 'anti_aliasing': aa,
