@@ -318,7 +318,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   auto launch_resample = [&](int e0, int e1, hipStream_t st) {
     const int blocks_x = p.cost_cnt ? SWB_COST_SHARDS * ((p.cost_cap + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK)
                                     : (e1 - e0 + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK;
-    const dim3 grid(blocks_x, p.nbands, p.ncg);
+    const dim3 grid(blocks_x, p.nbands, p.cost_cnt ? 1 : p.ncg);      // (cost-ordered: a list entry names its column group)
     hipLaunchKernelGGL(fn2, grid, dim3(SWB_WAVE * SWB_RS_WAVES_PER_BLOCK), lds2, st, p);
   };
   launch_cover(0, c.n_envs);
@@ -402,8 +402,8 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   // cost buckets: 32 of them over run lists of up to ~Hc units (longer lists share the last one)
   p.cost_shift = 0;
   while ((SWB_COST_BUCKETS << p.cost_shift) < p.Hc) ++p.cost_shift;
-  if (!getenv("SWB_NO_COST_ORDER")) {
-    p.cost_cap = (p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS;
+  if (!getenv("SWB_NO_COST_ORDER") && p.N < (1 << 24)) {
+    p.cost_cap = ((p.Wo + 63) / 64) * ((p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS);
     if (upload(&h->d_cost_cnt, (const uint32_t*)nullptr, 2 * SWB_COST_SHARDS * SWB_COST_BUCKETS) ||
         upload(&h->d_cost_list, (const int32_t*)nullptr, (size_t)2 * SWB_COST_SHARDS * SWB_COST_BUCKETS * p.cost_cap)) {
       swb_destroy(h);

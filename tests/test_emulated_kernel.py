@@ -104,6 +104,15 @@ def test_emulated_kernel_without_cost_ordered_dispatch(monkeypatch):
   monkeypatch.setenv('SWB_NO_COST_ORDER', '1')
   _run('cluster_s5', 11, 4, 5)
   _run('cluster_s5', 11, 3, 1)
+  _run('geom_256x64', 3, 2, 2)
+
+
+@pytest.mark.parametrize('name,aa', [('embodied_s12', 5), ('geom_256x64', 2), ('geom_128x128', 1)])
+def test_emulated_kernel_cost_order_files_every_column_group(name, aa):
+  """Images wider than 64 columns: every (environment, group of 64 columns) is a task of its own in the cost-ordered lists,
+  filed under the length of that group's run list."""
+  for n in (1, 7, 9):
+    _run(name, n, 2, aa)
 
 
 @pytest.mark.parametrize('name,aa', [('cluster_s5', 5), ('cluster_s5', 1)])

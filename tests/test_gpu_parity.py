@@ -155,9 +155,18 @@ def test_cost_ordered_dispatch_covers_every_environment(n_envs):
   _run('cluster_s5', n_envs, 2, 1)
 
 
+@pytest.mark.parametrize('name,aa', [('embodied_s12', 5), ('geom_256x64', 2), ('geom_128x128', 1)])
+@pytest.mark.parametrize('n_envs', [1, 7, 33, 250])
+def test_cost_ordered_dispatch_files_every_column_group(name, aa, n_envs):
+  """Images wider than 64 columns: every (environment, group of 64 columns) is a task of its own in the cost-ordered lists,
+  filed under the length of that group's run list (2 and 4 groups; resample and fill kernels)."""
+  _run(name, n_envs, 3, aa)
+
+
 def test_without_cost_ordered_dispatch(monkeypatch):
   monkeypatch.setenv('SWB_NO_COST_ORDER', '1')
   _run('cluster_s5', 100, 4, 5)
+  _run('geom_256x64', 9, 2, 2)
 
 
 def test_run_list_overflow_is_flagged(monkeypatch):
