@@ -6,6 +6,7 @@
 #   4. the default `python bench.py` line (extras + cpu baseline)              -> $OUT/bench_default.json
 #   5. kernel traces of the AA = 1 and the 12-sprite 128x128 workloads
 #   6. wave timelines of both kernels (experiment build)                       -> $OUT/timeline_*.json
+#   7. kernel time by phase (experiment builds cut short after a phase)        -> $OUT/phase_times.md
 # usage: tools/r03_final.sh [TAG]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -56,5 +57,9 @@ if [ -f spriteworld_amd/csrc/exp_trace.so ]; then
   SWB_LIBRARY=$PWD/spriteworld_amd/csrc/exp_trace.so python tools/exp_trace.py cluster_s5 8192 5 $OUT/timeline_8192.json > $OUT/timeline_8192.log 2>&1
   SWB_LIBRARY=$PWD/spriteworld_amd/csrc/exp_trace.so python tools/exp_trace.py cluster_s5 65536 5 $OUT/timeline_65536.json > $OUT/timeline_65536.log 2>&1
   rm -f $OUT/*_trace.npy
+fi
+stamp "phase profile"
+if [ -f spriteworld_amd/csrc/exp_phase1.so ]; then
+  timeout 200 python tools/phase_profile.py $OUT/phase_times.md cluster_s5:5 cluster_s5:1 embodied_s12:5 > $OUT/phase_profile.log 2>&1
 fi
 stamp "done"
