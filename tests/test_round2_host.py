@@ -81,7 +81,7 @@ def test_bench_line_carries_the_committed_counters_of_this_build():
   build_id = build.source_hash()[:16]
   for workload, aa, cover, kernel, image, sprites, a_bytes in (
       ('cluster_s5', 5, 'swb_cover_kernel<10>', 'swb_resample_kernel<6>', [64, 64], 5, 12461),
-      ('cluster_s5', 1, 'swb_cover_kernel<2>', 'swb_fill_kernel', [64, 64], 5, 12461),
+      ('cluster_s5', 1, 'swb_cover_kernel<2>', 'none (the cover kernel paints the frame)', [64, 64], 5, 12461),
       ('embodied_s12', 5, 'swb_cover_kernel<20>', 'swb_resample_kernel<6>', [128, 128], 12, 49513)):
     args = argparse.Namespace(envs_per_gpu=8192, gpus=1, steps=20, warmup=5, workload=workload, aa=aa)
     res = dict(elapsed=0.0046, kernel_ms=4.4, cover_ms=1.9, resample_ms=2.5, launches=20, a_bytes=a_bytes, errors=0,
@@ -95,9 +95,11 @@ def test_bench_line_carries_the_committed_counters_of_this_build():
       assert key in line, key
     r = line['roofline']
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
-    assert r['kernel'] == cover + ' + ' + kernel and r['build_id'] == build_id
+    one_kernel = kernel.startswith('none')          # anti_aliasing = 1, narrow image: the cover kernel is the whole step
+    assert r['kernel'] == (cover + ' (paints the frame: anti_aliasing = 1)' if one_kernel else cover + ' + ' + kernel)
+    assert r['build_id'] == build_id
     # the step's rate is taken over BOTH kernels; each kernel's own duration is listed, and they add up
-    assert [k['name'] for k in r['kernels']] == [cover, kernel]
+    assert [k['name'] for k in r['kernels']] == ([cover] if one_kernel else [cover, kernel])
     assert abs(sum(k['ms'] for k in r['kernels']) - r['kernel_ms']) < 1e-9
     assert abs(r['achieved'] - a_bytes * 8192 / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6
     counters = bench.profiled_counters(workload, 8192, aa, build_id)
@@ -107,7 +109,9 @@ def test_bench_line_carries_the_committed_counters_of_this_build():
     assert counters['kernel'] == r['kernel']
     assert r['traffic'] == counters['hbm_traffic_bytes_per_launch'] > a_bytes * 8192
     ins = r['instructions']
-    assert ins['insts_valu_per_env'] > 1000 and 0.2 < ins['valu_issue_frac_of_step'] < 1.0
+    assert ins['insts_valu_per_env'] > 1000 and ins['valu_issue_frac_of_step'] > 0.2
+    if workload == 'cluster_s5' and aa == 5:        # (the made-up kernel time above is about the headline's)
+      assert ins['valu_issue_frac_of_step'] < 1.0
     if ins['resample_valu_model_min_per_env']:
       assert 1.0 <= ins['resample_valu_measured_over_model'] < 2.0
     res['variant'] = dict(res['variant'], build_id='0000000000000000')
