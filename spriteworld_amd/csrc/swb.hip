@@ -410,6 +410,16 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
       return SWB_ERR_HIP;
     }
     p.cost_cnt = h->d_cost_cnt; p.cost_list = h->d_cost_list;
+    // rounds of the dealing = the compute units of an XCD (8 XCDs; a power of two on this part: 32)
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const int per_xcd = cus / SWB_COST_SHARDS;
+    // (only when every wave of the launch is resident at once: with several rounds of waves the heaviest tasks must simply
+    // come first -- measured on two rounds: +1...2 % with alternating rounds)
+    const long long waves = (long long)p.N * ((p.Wo + 63) / 64) * h->nbands;
+    if (per_xcd >= 2 && (per_xcd & (per_xcd - 1)) == 0 && waves <= (long long)cus * 4 * SWB_RS_WAVES_PER_SIMD && !getenv("SWB_NO_SNAKE"))
+      while ((1 << p.deal_shift) < per_xcd) ++p.deal_shift;
+    if (const char* x = getenv("SWB_DEAL_SHIFT")) p.deal_shift = std::max(0, atoi(x));      // tests: short rounds on small batches
   }
   p.run_cap = 4 * p.Hc;
   if (const char* x = getenv("SWB_RUN_CAP")) p.run_cap = std::max(8, atoi(x));      // tests

@@ -187,6 +187,7 @@ void run_grid(const std::function<void()>& body, dim3 grid, dim3 block, size_t l
       f.st.tid = dim3((unsigned)t, 0, 0);
       f.st.bid = dim3(b, by, bz);
       f.st.bdim = block;
+      f.st.gdim = grid;
       f.st.lane = t & 63;
     }
     for (int w = 0; w < (threads + 63) / 64; ++w) { g_waves[w] = wave_state(); }

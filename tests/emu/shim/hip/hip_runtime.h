@@ -43,7 +43,7 @@ inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 // ---------------------------------------------------------------- the emulator core (tests/emu/emu_runtime.cc)
 namespace emu {
-struct thread_state { dim3 tid, bid, bdim; int lane; };
+struct thread_state { dim3 tid, bid, bdim, gdim; int lane; };
 thread_state& self();                       // the running work-item
 // Rendezvous of the wave: deposits `in` (8 bytes), waits for every unfinished lane, returns the table of all
 // lanes' deposits (valid until this lane's next rendezvous) and, in *active, the mask of lanes that took part.
@@ -54,6 +54,7 @@ extern unsigned char smem[];                // the workgroup's LDS
 #define threadIdx (emu::self().tid)
 #define blockIdx (emu::self().bid)
 #define blockDim (emu::self().bdim)
+#define gridDim (emu::self().gdim)
 
 // ---------------------------------------------------------------- cross-lane operations
 namespace emu {

@@ -107,6 +107,18 @@ def test_emulated_kernel_without_cost_ordered_dispatch(monkeypatch):
   _run('geom_256x64', 3, 2, 2)
 
 
+@pytest.mark.parametrize('shift', ['1', '2'])
+def test_emulated_kernel_cost_order_dealt_in_alternating_rounds(monkeypatch, shift):
+  """The resample / fill blocks of a shard take its cost-ordered tasks in rounds of 2^deal_shift blocks, odd rounds in ascending
+  order (32 blocks per round on the GPU: the compute units of an XCD; SWB_DEAL_SHIFT shortens the rounds so that small batches
+  have several, with a short last one).  Every task is served exactly once."""
+  monkeypatch.setenv('SWB_DEAL_SHIFT', shift)
+  for n in (33, 70, 97):
+    _run('cluster_s5', n, 2, 5)
+  _run('geom_256x64', 21, 2, 2)
+  _run('geom_128x128', 35, 2, 1)
+
+
 @pytest.mark.parametrize('name,aa', [('embodied_s12', 5), ('geom_256x64', 2), ('geom_128x128', 1)])
 def test_emulated_kernel_cost_order_files_every_column_group(name, aa):
   """Images wider than 64 columns: every (environment, group of 64 columns) is a task of its own in the cost-ordered lists,

@@ -163,6 +163,18 @@ def test_cost_ordered_dispatch_files_every_column_group(name, aa, n_envs):
   _run(name, n_envs, 3, aa)
 
 
+@pytest.mark.parametrize('shift', ['1', '2', '5'])
+def test_cost_order_dealt_in_alternating_rounds(monkeypatch, shift):
+  """The resample / fill blocks of a shard take its cost-ordered tasks in rounds of 2^deal_shift blocks (5: the 32 compute units of
+  an XCD), odd rounds in ascending order; SWB_DEAL_SHIFT shortens the rounds.  Every task is served exactly once, whatever the
+  number of rounds and the length of the last one."""
+  monkeypatch.setenv('SWB_DEAL_SHIFT', shift)
+  for n in (33, 97, 1500, 3000):
+    _run('cluster_s5', n, 2, 5)
+  _run('geom_256x64', 300, 2, 2)
+  _run('geom_128x128', 700, 2, 1)
+
+
 def test_without_cost_ordered_dispatch(monkeypatch):
   monkeypatch.setenv('SWB_NO_COST_ORDER', '1')
   _run('cluster_s5', 100, 4, 5)

@@ -34,7 +34,12 @@ def apply(files, arg, replace_once):
                begin + '  const int o_lo = as_const(p.band_lo)[band], o_hi = as_const(p.band_lo)[band + 1];\n  if (o_lo >= o_hi) return;\n')
   replace_once(files, k, '      if (r_first >= o_hi) { more = false; break; }\n    }\n  }\n}\n',
                '      if (r_first >= o_hi) { more = false; break; }\n    }\n  }\n' +
-               end('(size_t)p.N * p.nbands + (size_t)env * p.nbands + band') + '}\n')
+               end('(size_t)p.N * p.nbands + (size_t)env * p.nbands + band') +
+               '  if (p.exp_trace && l == 0) {   // where the task ran: block, wave of the block; and what it cost: units of its list\n'
+               '    unsigned long long* t = p.exp_trace + ((size_t)p.N * p.nbands + (size_t)env * p.nbands + band) * 12;\n'
+               '    t[4] = blockIdx.x | ((unsigned long long)(threadIdx.x >> 6) << 32);\n'
+               '    t[5] = hdr[SWB_RHDR_GROUPS + g * SWB_RHDR_GSTRIDE];\n'
+               '  }\n' + '}\n')
   h = 'swb.hip'
   replace_once(files, h, 'const char* swb_last_error(void) { return g_err.c_str(); }\n',
                'const char* swb_last_error(void) { return g_err.c_str(); }\n'
