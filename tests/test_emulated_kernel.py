@@ -107,6 +107,32 @@ def test_emulated_kernel_without_cost_ordered_dispatch(monkeypatch):
   _run('geom_256x64', 3, 2, 2)
 
 
+@pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 19, 5), ('embodied_s12', 5, 5), ('ragged_s16', 13, 5), ('geom_128x128', 9, 1),
+                                            ('sorting_s4', 11, 5)])
+def test_emulated_cover_launches_in_cost_order(monkeypatch, name, n_envs, aa):
+  """Launches of more than one round of cover waves take the environments in order of what their cover wave cost in the previous
+  launch (cycle counts filed per environment, heavy scenes first); SWB_COVER_ORDER asks for it at any batch size.  The order is
+  only used after a launch that filed every environment: a step without an observation in between falls back to the plain order
+  for one launch.  State, rewards and frames do not depend on any of it."""
+  from oracle import oracle
+  monkeypatch.setenv('SWB_COVER_ORDER', '1')
+  _run(name, n_envs, 4, aa)
+  cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=3, seed=1, anti_aliasing=aa)
+  ora, eng = oracle.Engine(cfg, pool), _emu(cfg, pool)
+  rng = np.random.default_rng(7)
+  for t in range(6):
+    a = sample(rng)
+    want = ora.step(a)
+    eng.step(a, render=(t != 2))                     # launch 2 renders nothing and files nothing
+    if t == 2:
+      continue
+    got = eng.outputs_host()
+    np.testing.assert_array_equal(got['step_type'], want['step_type'])
+    np.testing.assert_array_equal(_bits(eng.state()['x']), _bits(ora.state()['x']))
+    assert np.array_equal(got['obs'], want['obs']), t
+  eng.close()
+
+
 @pytest.mark.parametrize('shift', ['1', '2'])
 def test_emulated_kernel_cost_order_dealt_in_alternating_rounds(monkeypatch, shift):
   """The resample / fill blocks of a shard take its cost-ordered tasks in rounds of 2^deal_shift blocks, odd rounds in ascending

@@ -163,6 +163,33 @@ def test_cost_ordered_dispatch_files_every_column_group(name, aa, n_envs):
   _run(name, n_envs, 3, aa)
 
 
+@pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 33, 5), ('cluster_s5', 6000, 5), ('embodied_s12', 300, 5), ('ragged_s16', 257, 5),
+                                            ('geom_128x128', 700, 1), ('sorting_s4', 1001, 5)])
+def test_cover_launches_in_cost_order(monkeypatch, name, n_envs, aa):
+  """Launches of more than one round of cover waves (6000 environments here) take the environments in order of what their cover
+  wave cost in the previous launch; SWB_COVER_ORDER asks for it at any batch size.  The order is only used after a launch that
+  filed every environment (a step without an observation in between: one launch in plain order)."""
+  from oracle import oracle
+  from spriteworld_amd import engine
+  monkeypatch.setenv('SWB_COVER_ORDER', '1')
+  _run(name, n_envs, 4, aa)
+  cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=3, seed=1, anti_aliasing=aa)
+  ora, eng = oracle.Engine(cfg, pool), engine.Engine(cfg, pool)
+  rng = np.random.default_rng(7)
+  for t in range(6):
+    a = sample(rng)
+    want = ora.step(a)
+    eng.step(a, render=(t != 2))                     # launch 2 renders nothing and files nothing
+    if t == 2:
+      continue
+    got = eng.outputs_host()
+    assert not got['error'].any()
+    np.testing.assert_array_equal(got['step_type'], want['step_type'])
+    np.testing.assert_array_equal(_bits(eng.state()['x']), _bits(ora.state()['x']))
+    assert np.array_equal(got['obs'], want['obs']), t
+  eng.close()
+
+
 @pytest.mark.parametrize('shift', ['1', '2', '5'])
 def test_cost_order_dealt_in_alternating_rounds(monkeypatch, shift):
   """The resample / fill blocks of a shard take its cost-ordered tasks in rounds of 2^deal_shift blocks (5: the 32 compute units of

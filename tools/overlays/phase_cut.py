@@ -12,3 +12,5 @@ def apply(files, arg, replace_once):
                '#define SWB_HOOK_PHASE_END(k) { if ((k) == %d) { if (lane_id() == 0) ovf_slot_release(p, ovf); return; } }\n' % cut)
   # no run lists are written: the second kernel must not run
   replace_once(files, 'swb.hip', '  if (p.obs && !p.paint_in_cover) launch_resample(0, c.n_envs, stream);\n', '  (void)launch_resample;\n')
+  # ... and no environment is filed for the order of the next cover launch: plain order
+  replace_once(files, 'swb.hip', '  h->cover_lists_filed = p.obs && !p.paint_in_cover && p.ccost_list;\n', '  h->cover_lists_filed = false;\n')
