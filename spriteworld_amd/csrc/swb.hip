@@ -321,6 +321,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     const long long slots = (long long)std::max(cus, 1) * 4 * (v->nw <= 10 ? SWB_COVER_WAVES_PER_SIMD : SWB_COVER_WAVES_PER_SIMD_WIDE);
     p.cover_order = (h->cover_lists_filed && p.ccost_list && ((p.N > slots && p.N <= 4 * slots) || getenv("SWB_COVER_ORDER"))) ? 1 : 0;
+    if (p.N > 2 * slots) p.prio_levels &= ~2;          // (cover waves' priorities: measured +1.3 % at three rounds of waves)
   }
   // (cost-ordered: block b serves rank b / 8 of shard b % 8; a shard holds up to cost_cap environments)
   auto launch_cover = [&](int e0, int e1) {
@@ -416,8 +417,16 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   while ((SWB_COST_BUCKETS << p.cost_shift) < p.Hc) ++p.cost_shift;
   if (!getenv("SWB_NO_COST_ORDER") && p.N < (1 << 24)) {
     p.cost_cap = ((p.Wo + 63) / 64) * ((p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS);
-    std::vector<uint32_t> cnt0(2 * 2 * SWB_COST_SHARDS * SWB_COST_BUCKETS + 1, 0u);
-    cnt0.back() = 12;            // bucket width of the cover kernel's cycle counts: 2^12 to begin with, adapted on the device
+    std::vector<uint32_t> cnt0(2 * 2 * SWB_COST_SHARDS * SWB_COST_BUCKETS + 3, 0u);
+    cnt0[SWB_COST_WORD_COVER_SHIFT] = 12;   // bucket width of the cover kernel's cycle counts: 2^12 to begin with, adapted on the device
+    // (priorities when the launch is at most two rounds of resample waves: in steady state they cost 0.8 %)
+    {
+      int cus2 = 0;
+      (void)hipDeviceGetAttribute(&cus2, hipDeviceAttributeMultiprocessorCount, device);
+      const long long waves = (long long)p.N * ((p.Wo + 63) / 64) * h->nbands;
+      p.prio_levels = (!getenv("SWB_NO_PRIO") && waves <= 2ll * std::max(cus2, 1) * 4 * SWB_RS_WAVES_PER_SIMD) ? 1 : 0;
+      if (!getenv("SWB_NO_COVER_PRIO")) p.prio_levels |= 2;          // (cover waves: only ever used with cover_order)
+    }
     const size_t ccap = (size_t)(p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS;
     if (upload(&h->d_cost_cnt, cnt0.data(), cnt0.size()) ||
         upload(&h->d_ccost_list, (const int32_t*)nullptr, (size_t)2 * SWB_COST_SHARDS * SWB_COST_BUCKETS * ccap) ||

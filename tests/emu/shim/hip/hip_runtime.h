@@ -119,6 +119,7 @@ void block_barrier(int line);               // s_barrier: every unfinished work-
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __syncthreads() emu::block_barrier(__LINE__)
 /* a clock that advances with every reading (the cover kernel orders the next launch by the cycles its waves took) */
+#define __builtin_amdgcn_s_setprio(level) ((void)0)
 inline unsigned long long __builtin_amdgcn_s_memtime() { static unsigned long long t = 0; return t += 997; }
 // v_perm_b32 D = bytes of {S0, S1} selected by S2: selector 0-3 = S1's bytes, 4-7 = S0's bytes (only these are used)
 inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel) {
