@@ -133,6 +133,15 @@ def test_emulated_cover_launches_in_cost_order(monkeypatch, name, n_envs, aa):
   eng.close()
 
 
+@pytest.mark.parametrize('seed', [1, 4, 6])
+def test_emulated_cover_cost_order_on_randomised_configurations(monkeypatch, seed):
+  """Random task / action space / geometry / sprite count configurations (the fuzz workloads) with the cost-ordered cover launch
+  and short dealing rounds switched on: the dispatch never changes a result."""
+  monkeypatch.setenv('SWB_COVER_ORDER', '1')
+  monkeypatch.setenv('SWB_DEAL_SHIFT', '1')
+  _run('fuzz_%d' % seed, 21, 4, 5, seed=seed)
+
+
 @pytest.mark.parametrize('shift', ['1', '2'])
 def test_emulated_kernel_cost_order_dealt_in_alternating_rounds(monkeypatch, shift):
   """The resample / fill blocks of a shard take its cost-ordered tasks in rounds of 2^deal_shift blocks, odd rounds in ascending
