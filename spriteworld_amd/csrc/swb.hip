@@ -94,7 +94,8 @@ struct swb_engine {
   uint32_t* d_cost_cnt = nullptr;
   int32_t* d_cost_list = nullptr;
   int32_t* d_ccost_list = nullptr;   // ... and the environments in order of the cover kernel's cost (swb_params::cover_order)
-  bool cover_lists_filed = false;    // the previous launch filed every environment (it rendered, through the run lists)
+  bool cover_lists_filed = false;    // the previous launch filed every environment (it rendered)
+  int launch_phase = 0;              // launch count % 3 (swb_params::cphase)
   int launch_parity = 0;
   // hand-off cover -> resample
   uint32_t *d_runs = nullptr, *d_rhdr = nullptr;
@@ -311,6 +312,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   }
   const size_t lds2 = p.AA == 1 ? 0 : (((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15);
   p.parity = h->launch_parity;
+  p.cphase = h->launch_phase;
   // anti_aliasing = 1, one column group: the cover kernel paints the frame itself, there is no second kernel
   p.paint_in_cover = (p.AA == 1 && p.ncg == 1 && p.obs && !getenv("SWB_NO_PAINT_IN_COVER")) ? 1 : 0;
   // environments in order of what their cover wave cost in the previous launch -- if that launch filed them all
@@ -338,10 +340,10 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   if (h->timing && !p.paint_in_cover) HIP_TRY(hipEventRecord(ev.e1, stream));
   if (p.obs && !p.paint_in_cover) launch_resample(0, c.n_envs, stream);
   HIP_TRY(hipGetLastError());
-  if (!p.obs && p.cost_cnt)       // no second kernel to clear the next launch's bucket counters
-    HIP_TRY(hipMemsetAsync(h->d_cost_cnt + (size_t)(p.parity ^ 1) * 2 * SWB_COST_SHARDS * SWB_COST_BUCKETS, 0,
-                           2 * SWB_COST_SHARDS * SWB_COST_BUCKETS * sizeof(uint32_t), stream));
-  h->cover_lists_filed = p.obs && !p.paint_in_cover && p.ccost_list;
+  if (!p.obs && p.cost_cnt)       // no second kernel to clear the next launch's bucket counters (kind 0; the cover kernel keeps kind 1)
+    HIP_TRY(hipMemsetAsync(h->d_cost_cnt + (size_t)(p.parity ^ 1) * SWB_COST_SET, 0, SWB_COST_SET * sizeof(uint32_t), stream));
+  h->cover_lists_filed = p.obs && p.ccost_list;
+  h->launch_phase = (h->launch_phase + 1) % 3;
   h->launch_parity ^= 1;
   if (h->timing) {
     if (p.paint_in_cover) HIP_TRY(hipEventRecord(ev.e1, stream));      // (no second kernel: the whole step is the cover kernel)
@@ -417,8 +419,10 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   while ((SWB_COST_BUCKETS << p.cost_shift) < p.Hc) ++p.cost_shift;
   if (!getenv("SWB_NO_COST_ORDER") && p.N < (1 << 24)) {
     p.cost_cap = ((p.Wo + 63) / 64) * ((p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS);
-    std::vector<uint32_t> cnt0(2 * 2 * SWB_COST_SHARDS * SWB_COST_BUCKETS + 3, 0u);
-    cnt0[SWB_COST_WORD_COVER_SHIFT] = 12;   // bucket width of the cover kernel's cycle counts: 2^12 to begin with, adapted on the device
+    std::vector<uint32_t> cnt0(5 * SWB_COST_SET + SWB_COST_WORDS, 0u);
+    for (int ph = 0; ph < 3; ++ph) cnt0[SWB_COST_WORD_COVER_SHIFT(ph)] = 12;   // bucket width of the cover kernel's cycle counts: 2^12 to begin with
+    p.prio_div = 4;              // (measured: levels of a quarter of a mean wave 2 % better than of half a wave, at 8192 environments)
+    if (const char* x = getenv("SWB_PRIO_DIV")) p.prio_div = std::max(1, atoi(x));
     // (priorities when the launch is at most two rounds of resample waves: in steady state they cost 0.8 %)
     {
       int cus2 = 0;
@@ -429,7 +433,7 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
     }
     const size_t ccap = (size_t)(p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS;
     if (upload(&h->d_cost_cnt, cnt0.data(), cnt0.size()) ||
-        upload(&h->d_ccost_list, (const int32_t*)nullptr, (size_t)2 * SWB_COST_SHARDS * SWB_COST_BUCKETS * ccap) ||
+        upload(&h->d_ccost_list, (const int32_t*)nullptr, (size_t)3 * SWB_COST_SHARDS * SWB_COST_BUCKETS * ccap) ||
         upload(&h->d_cost_list, (const int32_t*)nullptr, (size_t)2 * SWB_COST_SHARDS * SWB_COST_BUCKETS * p.cost_cap)) {
       swb_destroy(h);
       return SWB_ERR_HIP;

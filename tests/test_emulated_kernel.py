@@ -108,7 +108,7 @@ def test_emulated_kernel_without_cost_ordered_dispatch(monkeypatch):
 
 
 @pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 19, 5), ('embodied_s12', 5, 5), ('ragged_s16', 13, 5), ('geom_128x128', 9, 1),
-                                            ('sorting_s4', 11, 5)])
+                                            ('sorting_s4', 11, 5), ('cluster_s5', 13, 1), ('tiny_s6', 7, 1)])
 def test_emulated_cover_launches_in_cost_order(monkeypatch, name, n_envs, aa):
   """Launches of more than one round of cover waves take the environments in order of what their cover wave cost in the previous
   launch (cycle counts filed per environment, heavy scenes first); SWB_COVER_ORDER asks for it at any batch size.  The order is

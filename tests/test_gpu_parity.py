@@ -164,7 +164,7 @@ def test_cost_ordered_dispatch_files_every_column_group(name, aa, n_envs):
 
 
 @pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 33, 5), ('cluster_s5', 6000, 5), ('embodied_s12', 300, 5), ('ragged_s16', 257, 5),
-                                            ('geom_128x128', 700, 1), ('sorting_s4', 1001, 5)])
+                                            ('geom_128x128', 700, 1), ('sorting_s4', 1001, 5), ('cluster_s5', 6000, 1), ('tiny_s6', 333, 1)])
 def test_cover_launches_in_cost_order(monkeypatch, name, n_envs, aa):
   """Launches of more than one round of cover waves (6000 environments here) take the environments in order of what their cover
   wave cost in the previous launch; SWB_COVER_ORDER asks for it at any batch size.  The order is only used after a launch that

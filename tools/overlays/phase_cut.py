@@ -13,4 +13,4 @@ def apply(files, arg, replace_once):
   # no run lists are written: the second kernel must not run
   replace_once(files, 'swb.hip', '  if (p.obs && !p.paint_in_cover) launch_resample(0, c.n_envs, stream);\n', '  (void)launch_resample;\n')
   # ... and no environment is filed for the order of the next cover launch: plain order
-  replace_once(files, 'swb.hip', '  h->cover_lists_filed = p.obs && !p.paint_in_cover && p.ccost_list;\n', '  h->cover_lists_filed = false;\n')
+  replace_once(files, 'swb.hip', '  h->cover_lists_filed = p.obs && p.ccost_list;\n', '  h->cover_lists_filed = false;\n')
