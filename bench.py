@@ -20,14 +20,20 @@ roofline:     a step is two kernels on one stream (cover: state + geometry + cov
               and `config` are derived from what ran (swb_variant / the lowered config); `traffic` and
               `instructions` come from the committed PMC passes of exactly this build
               (profiles/r03_counters.json, keyed by the library's build id) or are null.
-cpu_baseline: the CPU oracle (a C port of the reference algorithm, oracle/sw_oracle.c) stepping a
-              bounded sample of the same workload on all host cores of rank 0, with the rate of the
-              UNMODIFIED reference on all cores of the build container beside it
-              (profiles/r03_reference_cpu_all_cores.json, tools/reference_cpu_baseline.py).
+cpu_baseline: kind "reference" -- the UNMODIFIED reference (Python + PIL + matplotlib + sklearn; on the GPU node the
+              sourceless bytecode of /root/reference under oracle/_ref, oracle/stage_ref.py) stepping a bounded sample
+              of the headline scene on ALL host cores of rank 0 in this same run (tools/reference_cpu_baseline.py:
+              one process per core, core count and CPU model in the block), with the C port of the same algorithm
+              (oracle/sw_oracle.c, threads) beside it as `port`.  Falls back to kind "port" -- with the reason --
+              only when the reference or one of its libraries cannot be imported.
+verified_envs: after the timed region the last step's positions, rewards, step types and frames of 64 sampled
+              environments are compared with the oracle stepped through the same actions (outside the timed region).
 """
 import argparse
+import copy
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -49,10 +55,6 @@ def algorithmic_bytes(cfg):
   return 3 * cfg.image_h * cfg.image_w + 28 * cfg.max_sprites + 17 + action_bytes
 
 
-# Survey-time rate of the unmodified reference (Python + PIL + sklearn) on one host core, BASELINE.md section 2.
-# /root/reference does not exist on the GPU box, so the same-run CPU baseline is the C port (oracle/sw_oracle.c),
-# which is 3-9x faster per core than the reference; both figures are put in the line.
-REFERENCE_RATE_PER_CORE = {'cluster_s5': 228.0, 'goal_s5': 637.0, 'embodied_s12': 156.0}
 VALU_CYCLES_PER_INST = 4.24      # profiles/r02_ubench_valu.md + SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the step kernels
 
 
@@ -73,46 +75,107 @@ def profiled_counters(workload, envs, aa, build_id):
   return None
 
 
-def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None):
+def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None, verify=0):
   """One timed run.  `gate` (N > 1): called after the warm-up, returns False when another rank failed to set up -- then
-  nothing is timed and None is returned (every rank leaves together instead of hanging in the barrier)."""
+  nothing is timed and None is returned (every rank leaves together instead of hanging in the barrier).
+  `verify` > 0: the final state / outputs of that many sampled environments are kept for verify_against_oracle()."""
   import torch
   from spriteworld_amd import engine, workloads
   cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=4, seed=seed, anti_aliasing=aa)
   eng = engine.Engine(cfg, pool, device=device)
   rng = np.random.default_rng(2000 + seed)
-  acts = [torch.as_tensor(sample(rng), device=eng.device) for _ in range(N_ACTION_SETS)]
+  acts_host = [sample(rng) for _ in range(N_ACTION_SETS)]
+  acts = [torch.as_tensor(a, device=eng.device) for a in acts_host]
   for i in range(warmup):
     eng.step(acts[i % N_ACTION_SETS])
   torch.cuda.synchronize(eng.device)
   if gate is not None and not gate(None):
     eng.close()
     return None
+  # from here on every rank runs the same sequence of collectives whatever happens on it: an exception in the timed
+  # region is carried in the result (`error`) instead of being raised past the barrier the other ranks are waiting in
+  run_error = None
   eng.timing(True)
   if barrier:
     barrier()
   torch.cuda.synchronize(eng.device)
   t0 = time.perf_counter()
-  for i in range(steps):
-    eng.step(acts[i % N_ACTION_SETS])
-  torch.cuda.synchronize(eng.device)
+  try:
+    for i in range(steps):
+      eng.step(acts[i % N_ACTION_SETS])
+    torch.cuda.synchronize(eng.device)
+  except Exception as e:  # pylint: disable=broad-except
+    run_error = repr(e)
   if barrier:
     barrier()
     torch.cuda.synchronize(eng.device)
   elapsed = time.perf_counter() - t0
-  kernel_ms, launches = eng.step_time_ms()
-  cover_ms, resample_ms, _ = eng.kernel_times_ms()
-  eng.timing(False)
-  errors = int(eng.error.max().item())
-  a_bytes = algorithmic_bytes(cfg)
-  variant = eng.variant()
-  facts = dict(sprites=cfg.max_sprites, image=[cfg.image_w, cfg.image_h], anti_aliasing=cfg.anti_aliasing,
-               action_space={0: 'SelectMove', 1: 'DragAndDrop', 2: 'Embodied'}[cfg.action_space],
-               task={0: 'NoReward', 1: 'FindGoalPosition', 2: 'Clustering'}[cfg.tasks[0].kind] if not cfg.is_meta
-               else 'MetaAggregated', max_episode_length=cfg.max_episode_length)
-  eng.close()
+  if run_error is not None:
+    return dict(error=run_error, elapsed=elapsed, kernel_ms=0.0, cover_ms=0.0, resample_ms=0.0, launches=0, errors=-1)
+  try:
+    kernel_ms, launches = eng.step_time_ms()
+    cover_ms, resample_ms, _ = eng.kernel_times_ms()
+    eng.timing(False)
+    errors = int(eng.error.max().item())
+    a_bytes = algorithmic_bytes(cfg)
+    variant = eng.variant()
+    sample_out = None
+    if verify:
+      idx = np.sort(np.random.default_rng(99 + seed).choice(n_envs, size=min(verify, n_envs), replace=False))
+      got, st = eng.outputs_host(), eng.state()
+      sample_out = dict(idx=idx, cfg=cfg, pool=pool, warmup=warmup, steps=steps,
+                        actions=[np.ascontiguousarray(a[idx]) for a in acts_host],
+                        got={k: got[k][idx].copy() for k in ('obs', 'reward', 'step_type', 'success', 'discount')},
+                        state={k: st[k][idx].copy() for k in ('x', 'y', 'step_count', 'episode', 'n_sprites')})
+    facts = dict(sprites=cfg.max_sprites, image=[cfg.image_w, cfg.image_h], anti_aliasing=cfg.anti_aliasing,
+                 action_space={0: 'SelectMove', 1: 'DragAndDrop', 2: 'Embodied'}[cfg.action_space],
+                 task={0: 'NoReward', 1: 'FindGoalPosition', 2: 'Clustering'}[cfg.tasks[0].kind] if not cfg.is_meta
+                 else 'MetaAggregated', max_episode_length=cfg.max_episode_length)
+    eng.close()
+  except Exception as e:  # pylint: disable=broad-except
+    return dict(error=repr(e), elapsed=elapsed, kernel_ms=0.0, cover_ms=0.0, resample_ms=0.0, launches=0, errors=-1)
   return dict(elapsed=elapsed, kernel_ms=kernel_ms, cover_ms=cover_ms, resample_ms=resample_ms, launches=launches,
-              a_bytes=a_bytes, errors=errors, variant=variant, facts=facts)
+              a_bytes=a_bytes, errors=errors, variant=variant, facts=facts, sample=sample_out, error=None)
+
+
+def verify_against_oracle(sample):
+  """The in-run check of the timed run: the oracle (checker; outside the timed region) replays the sampled environments
+  through exactly the actions the engine saw -- warm-up and timed steps -- and the LAST step's positions, step counts,
+  rewards, step types, success flags and frames must agree bit for bit (frames: differing bytes are counted)."""
+  import ctypes as C
+  from oracle import oracle
+  idx = sample['idx']
+  n = len(idx)
+  cfg = type(sample['cfg']).from_buffer_copy(bytes(sample['cfg']))
+  cfg.n_envs = n
+  pool = copy.copy(sample['pool'])
+  pool.pool_base = np.ascontiguousarray(sample['pool'].pool_base[idx])
+  pool.pool_len = np.ascontiguousarray(sample['pool'].pool_len[idx])
+  ora = oracle.Engine(cfg, pool)
+  t0 = time.perf_counter()
+  out = None
+  for k in (sample['warmup'], sample['steps']):          # the engine cycles the action sets from 0 in both regions
+    for i in range(k):
+      out = ora.step(sample['actions'][i % N_ACTION_SETS])
+  st = ora.state()
+  got, gst = sample['got'], sample['state']
+  bad = np.zeros(n, bool)
+  for key in ('x', 'y'):
+    bad |= (gst[key].view(np.uint64) != st[key].view(np.uint64)).any(axis=1)
+  for key in ('step_count', 'episode', 'n_sprites'):
+    bad |= gst[key] != st[key]
+  bad |= got['step_type'] != out['step_type']
+  bad |= got['success'] != out['success']
+  rg, ro = got['reward'], out['reward']
+  bad |= ~((np.isnan(rg) & np.isnan(ro)) | (rg.view(np.uint64) == ro.view(np.uint64)))
+  frame_bytes = int((got['obs'] != out['obs']).sum())
+  max_lsb = int(np.abs(got['obs'].astype(np.int16) - out['obs'].astype(np.int16)).max()) if n else 0
+  bad |= (got['obs'] != out['obs']).reshape(n, -1).any(axis=1)
+  import zlib
+  return {'verified_envs': int(n), 'mismatches': int(bad.sum()), 'frame_bytes_differing': frame_bytes,
+          'frame_max_abs_diff': max_lsb, 'steps_replayed': int(sample['warmup'] + sample['steps']),
+          'frames_crc32': '%08x' % zlib.crc32(np.ascontiguousarray(got['obs']).tobytes()),
+          'checker': 'oracle/sw_oracle.c through the same actions, after the timed region (%.1f s)' % (time.perf_counter() - t0)}
 
 
 def gpu_run_groups(name, n_envs, groups, steps, warmup, aa, device):
@@ -162,8 +225,8 @@ def usable_cores():
   return cores
 
 
-def cpu_baseline(name, aa, budget_s=12.0):
-  """Oracle env-steps/s on all host cores (threads; the C calls release the GIL)."""
+def port_cpu_baseline(name, aa, budget_s=6.0):
+  """The C port of the reference algorithm (oracle/sw_oracle.c) on all host cores (threads; the C calls release the GIL)."""
   from concurrent.futures import ThreadPoolExecutor
   from oracle import oracle
   from spriteworld_amd import workloads
@@ -195,22 +258,53 @@ def cpu_baseline(name, aa, budget_s=12.0):
       one_step(sample(rng))
       steps += 1
     dt = time.perf_counter() - t0
-  out = dict(value=n_envs * steps / dt, unit='env-steps/s', cores=cores, kind='port',
-             sample='%d envs x %d steps of %s (AA=%d) with oracle/sw_oracle.c on %d threads, %.1f s' %
-             (n_envs, steps, name, aa, cores, dt))
-  ref_path = os.path.join(ROOT, 'profiles', 'r03_reference_cpu_all_cores.json')
-  if name == WORKLOAD and aa == 5 and os.path.exists(ref_path):
-    with open(ref_path) as f:
-      ref = json.load(f)
-    out['reference_all_cores'] = {k: ref[k] for k in ('env_steps_per_s_all_cores', 'env_steps_per_s_per_core', 'processes', 'cpu',
-                                                       'where', 'envs', 'timed_steps_per_env')}
-    out['reference_all_cores']['source'] = 'profiles/r03_reference_cpu_all_cores.json (tools/reference_cpu_baseline.py)'
-  if name in REFERENCE_RATE_PER_CORE and aa == 5:
-    out['reference_env_steps_per_s_per_core'] = REFERENCE_RATE_PER_CORE[name]
-    out['reference_note'] = ('the unmodified Python reference measured %.0f env-steps/s on one core for this config '
-                             '(BASELINE.md section 2, survey container); it cannot run on the GPU box, so the timed '
-                             'baseline here is its C port' % REFERENCE_RATE_PER_CORE[name])
-  return out
+  return dict(value=n_envs * steps / dt, unit='env-steps/s', cores=cores, kind='port',
+              sample='%d envs x %d steps of %s (AA=%d) with oracle/sw_oracle.c on %d threads, %.1f s' %
+              (n_envs, steps, name, aa, cores, dt))
+
+
+def reference_cpu_baseline(envs_per_core=8, steps=300, warmup=20, timeout_s=240):
+  """The UNMODIFIED reference on every usable core of THIS host, in this run: tools/reference_cpu_baseline.py as a child
+  process (a fresh interpreter -- nothing forks beside the HIP context), one worker process per core, each stepping
+  `envs_per_core` reference Environments of the headline scene (BASELINE configs[2]) for `warmup` + `steps` steps.
+  Returns (block, None) or (None, reason)."""
+  from oracle import ref_harness
+  if not ref_harness.reference_available():
+    return None, 'reference not present: neither /root/reference nor oracle/_ref (python oracle/stage_ref.py)'
+  cores = usable_cores()
+  env = dict(os.environ, SWB_REF_WHERE='the bench host (GPU node when a GPU is visible): %s' % os.uname().nodename,
+             SPRITEWORLD_REFERENCE=ref_harness.REFERENCE_ROOT)
+  cmd = [sys.executable, os.path.join(ROOT, 'tools', 'reference_cpu_baseline.py'), str(envs_per_core * cores), str(steps),
+         str(warmup), str(cores)]
+  try:
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+  except subprocess.TimeoutExpired:
+    return None, 'reference baseline timed out after %d s' % timeout_s
+  if proc.returncode != 0:
+    return None, 'reference baseline failed: ' + (proc.stderr.strip().splitlines() or ['?'])[-1][:300]
+  rec = json.loads(proc.stdout)
+  block = dict(value=rec['env_steps_per_s_all_cores'], unit='env-steps/s', cores=rec['processes'], kind='reference',
+               per_core=rec['env_steps_per_s_per_core'], cpu=rec['cpu'], host_cpus=rec['host_cpus'],
+               sample='%d reference Environments (%d per process, %d processes = usable cores) x %d timed steps of the headline '
+                      'scene (5 sprites, 2 hue clusters, SelectMove, Clustering, 64x64 AA=5) after %d warm-up steps; slowest '
+                      'worker %.1f s' % (rec['envs'], envs_per_core, rec['processes'], rec['timed_steps_per_env'],
+                                         rec['warmup_steps_per_env'], rec['timed_seconds_slowest_worker']),
+               reference=dict(root=rec['reference_root'], kind=rec['reference_kind'], third_party=rec['third_party'],
+                              frame_checksum=rec['frame_checksum']),
+               where=rec['where'])
+  return block, None
+
+
+def cpu_baseline(name, aa):
+  """The reference itself on the host's cores (kind "reference") with the C port beside it; kind "port" when the reference
+  cannot run here (reason given).  The reference leg is the headline scene (configs[2]) whatever `name` is."""
+  port = port_cpu_baseline(name, aa)
+  ref, why = reference_cpu_baseline()
+  if ref is None:
+    port['reference_error'] = why
+    return port
+  ref['port'] = port
+  return ref
 
 
 def assemble_line(args, res, elapsed):
@@ -309,6 +403,7 @@ def main():
   ap.add_argument('--aa', type=int, default=5)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extra', action='store_true')
+  ap.add_argument('--no-verify', action='store_true', help='skip the oracle check of 64 sampled environments after the timed region')
   ap.add_argument('--gather-obs', action='store_true',
                   help='also all-gather the observation shards over RCCL every step (BASELINE configs[3])')
   args = ap.parse_args()
@@ -352,16 +447,25 @@ def main():
     return not setup_errors
 
   res = None
+  gated = [False]                            # this rank has been through the gate (set by the wrapper below)
+
+  def gate_once(error):
+    gated[0] = True
+    return gate(error)
+
   try:
     res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
-                  barrier=barrier, seed=rank, gate=gate if dist is not None else None)
+                  barrier=barrier, seed=rank, gate=gate_once if dist is not None else None,
+                  verify=64 if (rank == 0 and not args.no_verify) else 0)
   except Exception as e:  # pylint: disable=broad-except
     if dist is None:
       raise
-    if not setup_errors:                    # failed before the gate: tell the others (they are waiting in it)
-      gate('rank %d: %r' % (rank, e))
-    else:
-      setup_errors.append((rank, repr(e)))
+    if not gated[0]:                        # failed before the gate: tell the others (they are waiting in it)
+      gate_once('rank %d: %r' % (rank, e))
+    # (after the gate gpu_run raises nothing: failures of the timed region come back in res['error'], so that every
+    # rank runs the same collectives below)
+  if dist is None and res is not None and res.get('error'):
+    raise SystemExit('timed region failed: ' + res['error'])
   per_rank = None
   elapsed = res['elapsed'] if res else None
   if dist is not None and res is not None:
@@ -373,7 +477,11 @@ def main():
     dist.all_gather_object(per_rank, {'rank': rank, 'device': torch.cuda.get_device_name(device), 'local_device': device,
                                       'elapsed_s': res['elapsed'], 'kernel_ms': res['kernel_ms'] / n_l,
                                       'cover_ms': res['cover_ms'] / n_l, 'resample_ms': res['resample_ms'] / n_l,
-                                      'env_errors': res['errors']})
+                                      'env_errors': res['errors'], 'error': res.get('error')})
+    failed = [(r['rank'], r['error']) for r in per_rank if r.get('error')]
+    if failed:                               # some rank failed inside the timed region: no value, one line with the errors
+      setup_errors[:] = failed
+      res = None
 
   gather = None
   if args.gather_obs and dist is not None and res is not None:
@@ -400,6 +508,11 @@ def main():
     return
 
   out = assemble_line(args, res, elapsed)
+  if res.get('sample') is not None:
+    try:
+      out.update(verify_against_oracle(res['sample']))
+    except Exception as e:  # pylint: disable=broad-except
+      out.update({'verified_envs': 0, 'mismatches': None, 'verify_error': repr(e)})
   if dist is not None:
     # what torch.distributed itself saw (the driver can check that RCCL really ran N ranks) and every rank's own kernel time
     out['world_size'] = dist.get_world_size()

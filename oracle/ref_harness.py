@@ -8,19 +8,50 @@ Imports `/root/reference/spriteworld` read-only under the three shims SURVEY.md
                                          spriteworld/renderers/pil_renderer.py:84;
   3. `np.cast[dtype]` shim            -- removed in numpy 2, used at
                                          spriteworld/factor_distributions.py:102.
-`/root/reference` exists only in the build container; on the GPU box
-`reference_available()` is False and every caller must skip.  Nothing in the
-product package (`spriteworld_amd/`) imports this module.
+`/root/reference` exists only in the build container.  Where it is absent (the GPU box) the loader falls
+back to `oracle/_ref/`: the same unmodified modules as sourceless bytecode, compiled from the sources where
+they lie by `oracle/stage_ref.py` (run by `__graft_entry__.build()`; a git-ignored build output that travels
+with the tree like the built `.so` files).  `reference_available()` is False only when neither exists.
+Nothing in the product package (`spriteworld_amd/`) imports this module.
 """
 import os
 import sys
 
-REFERENCE_ROOT = os.environ.get('SPRITEWORLD_REFERENCE', '/root/reference')
-_COMPAT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'compat')
+_HERE = os.path.dirname(os.path.abspath(__file__))
+STAGED_ROOT = os.path.join(_HERE, '_ref')
+_COMPAT = os.path.join(_HERE, 'compat')
+
+
+def _pick_root():
+  env = os.environ.get('SPRITEWORLD_REFERENCE')
+  for root in ([env] if env else []) + ['/root/reference', STAGED_ROOT]:
+    if os.path.isdir(os.path.join(root, 'spriteworld')):
+      return root
+  return env or '/root/reference'
+
+
+REFERENCE_ROOT = _pick_root()
 
 
 def reference_available():
   return os.path.isdir(os.path.join(REFERENCE_ROOT, 'spriteworld'))
+
+
+def reference_kind():
+  """'source' (the tree itself) or 'bytecode' (oracle/_ref, compiled from it by oracle/stage_ref.py)."""
+  return 'bytecode' if os.path.abspath(REFERENCE_ROOT) == os.path.abspath(STAGED_ROOT) else 'source'
+
+
+def third_party_versions():
+  """Versions of the libraries whose arithmetic the reference delegates to, as imported here."""
+  import importlib
+  out = {}
+  for name, mod in (('numpy', 'numpy'), ('pillow', 'PIL'), ('matplotlib', 'matplotlib'), ('scikit-learn', 'sklearn')):
+    try:
+      out[name] = importlib.import_module(mod).__version__
+    except Exception as e:  # pylint: disable=broad-except
+      out[name] = 'missing: %r' % (e,)
+  return out
 
 
 def load_reference():

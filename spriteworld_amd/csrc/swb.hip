@@ -110,6 +110,10 @@ struct swb_engine {
   bool timing = false;
   struct step_events { hipEvent_t e0, e1, e2; };     // before cover, between the kernels, after resample / fill
   std::vector<step_events> events;
+  std::vector<step_events> event_pool;               // events of flushed steps, reused (no hipEventCreate per step)
+  // read once at swb_create (never per launch): the device's compute units and the test / A-B switches of the environment
+  int cus = 0;
+  bool no_paint_in_cover = false, force_cover_order = false;
   double timed_ms = 0.0, timed_cover_ms = 0.0;
   int64_t timed_launches = 0;
 };
@@ -248,9 +252,7 @@ int flush_timing(swb_engine* h) {
     h->timed_ms += ms;
     h->timed_cover_ms += ms_cover;
     h->timed_launches += 1;
-    (void)hipEventDestroy(ev.e0);
-    (void)hipEventDestroy(ev.e1);
-    (void)hipEventDestroy(ev.e2);
+    h->event_pool.push_back(ev);
   }
   h->events.clear();
   return 0;
@@ -305,24 +307,25 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   }
   swb_engine::step_events ev = {nullptr, nullptr, nullptr};
   if (h->timing) {
-    HIP_TRY(hipEventCreate(&ev.e0));
-    HIP_TRY(hipEventCreate(&ev.e1));
-    HIP_TRY(hipEventCreate(&ev.e2));
+    if (!h->event_pool.empty()) { ev = h->event_pool.back(); h->event_pool.pop_back(); }
+    else {
+      HIP_TRY(hipEventCreate(&ev.e0));
+      HIP_TRY(hipEventCreate(&ev.e1));
+      HIP_TRY(hipEventCreate(&ev.e2));
+    }
     HIP_TRY(hipEventRecord(ev.e0, stream));
   }
   const size_t lds2 = p.AA == 1 ? 0 : (((size_t)p.h_pfx_len * 4 + 15) & ~(size_t)15);
   p.parity = h->launch_parity;
   p.cphase = h->launch_phase;
   // anti_aliasing = 1, one column group: the cover kernel paints the frame itself, there is no second kernel
-  p.paint_in_cover = (p.AA == 1 && p.ncg == 1 && p.obs && !getenv("SWB_NO_PAINT_IN_COVER")) ? 1 : 0;
+  p.paint_in_cover = (p.AA == 1 && p.ncg == 1 && p.obs && !h->no_paint_in_cover) ? 1 : 0;
   // environments in order of what their cover wave cost in the previous launch -- if that launch filed them all
   // (and the launch is more than one round of cover waves but not many: one round needs no order, and from about a dozen
   // rounds on the plain order was measured 1.6 % faster)
   {
-    int cus = 0;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-    const long long slots = (long long)std::max(cus, 1) * 4 * (v->nw <= 10 ? SWB_COVER_WAVES_PER_SIMD : SWB_COVER_WAVES_PER_SIMD_WIDE);
-    p.cover_order = (h->cover_lists_filed && p.ccost_list && ((p.N > slots && p.N <= 4 * slots) || getenv("SWB_COVER_ORDER"))) ? 1 : 0;
+    const long long slots = (long long)std::max(h->cus, 1) * 4 * (v->nw <= 10 ? SWB_COVER_WAVES_PER_SIMD : SWB_COVER_WAVES_PER_SIMD_WIDE);
+    p.cover_order = (h->cover_lists_filed && p.ccost_list && ((p.N > slots && p.N <= 4 * slots) || h->force_cover_order)) ? 1 : 0;
     if (p.N > 2 * slots) p.prio_levels &= ~2;          // (cover waves' priorities: measured +1.3 % at three rounds of waves)
   }
   // (cost-ordered: block b serves rank b / 8 of shard b % 8; a shard holds up to cost_cap environments)
@@ -381,6 +384,9 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   swb_engine* h = new swb_engine();
   h->cfg = *cfg;
   h->device = device;
+  (void)hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device);
+  h->no_paint_in_cover = getenv("SWB_NO_PAINT_IN_COVER") != nullptr;
+  h->force_cover_order = getenv("SWB_COVER_ORDER") != nullptr;
   swb_params& p = h->p;
   memset(&p, 0, sizeof(p));
   p.N = cfg->n_envs; p.S = cfg->max_sprites; p.AA = cfg->anti_aliasing;
@@ -480,7 +486,8 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
 int swb_destroy(swb_handle h) {
   if (!h) return SWB_OK;
   (void)hipSetDevice(h->device);
-  for (auto& ev : h->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
+  for (auto* list : {&h->events, &h->event_pool})
+    for (auto& ev : *list) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
   void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
@@ -1115,7 +1122,7 @@ int swb_variant(swb_handle h, swb_variant_info* out) {
   out->n_bands = h->p.nbands ? h->p.nbands : h->nbands;
   out->n_column_groups = (h->p.Wo + 63) / 64;
   out->run_cap = h->p.run_cap;
-  out->paint_in_cover = (h->p.AA == 1 && (h->p.Wo + 63) / 64 == 1 && !getenv("SWB_NO_PAINT_IN_COVER")) ? 1 : 0;
+  out->paint_in_cover = (h->p.AA == 1 && (h->p.Wo + 63) / 64 == 1 && !h->no_paint_in_cover) ? 1 : 0;
   return SWB_OK;
 }
 

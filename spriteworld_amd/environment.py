@@ -343,8 +343,7 @@ class EnvironmentGroups(object):
   """`num_groups` independent BatchedEnvironments of `num_envs // num_groups` environments, each on its own
   HIP stream: the double-buffered stepping of RL samplers (the policy works on one group's observations while
   another group steps).  Work of different groups is unordered, so consecutive steps of different groups
-  overlap on the GPU and hide each launch's fill and drain (26 M -> 33 M env-steps/s at 8192 envs, bench.py
-  `extra`).  Each group's `global_env_offset` is set, so device-side reset sampling draws the episodes of
+  overlap on the GPU and hide each launch's fill and drain (bench.py `extra`, `*_2_groups_2_streams`).  Each group's `global_env_offset` is set, so device-side reset sampling draws the episodes of
   one `num_envs` batch."""
 
   def __init__(self, num_groups=2, num_envs=2, device=0, **kwargs):
@@ -449,13 +448,61 @@ class Environment(object):
       self._reset_next_step = True
     return ts
 
+  # ---- the rest of the reference's public surface (environment.py:80-86,110-142), acting on the device state
+  def _ensure_started(self):
+    """The reference's constructor already holds sprites (`self._sprites = self._init_sprites()`, environment.py:68), so
+    its introspection methods work before the first step; here the first episode is put on the device instead.  The first
+    `step()` still resets (environment.py:90-91) and draws the next episode, as the reference does."""
+    if self._episodes_used == 0:
+      self._maybe_refill()
+      self._batched.reset()
+
+  def success(self):
+    """environment.py:80-81: `task.success(sprites)` of the current sprites -- the flag the cover kernel evaluated when it
+    last changed them (task evaluation is part of every step and reset)."""
+    self._ensure_started()
+    return bool(self._batched.engine.success[0].item())
+
+  def should_terminate(self):
+    """environment.py:83-86."""
+    self._ensure_started()
+    timeout = self._batched.engine.env_state(0)['step_count'] >= self._batched._max_episode_length  # pylint: disable=protected-access
+    out_of_frame = any([s.out_of_frame for s in self.sprites])
+    return self.success() or out_of_frame or timeout
+
+  def sample_contained_position(self):
+    """environment.py:110-126: a random sprite (np.random.randint), then a random position inside it."""
+    sprites = self.sprites
+    return sprites[np.random.randint(len(sprites))].sample_contained_position()
+
+  def observation(self):
+    """environment.py:136-142: every renderer's view of the current state, rendered now (swb_render: the cover and
+    resample kernels without a state change), as numpy values."""
+    self._ensure_started()
+    obs = {}
+    for k, v in self._batched.observation().items():
+      a = v[0].cpu().numpy()
+      obs[k] = bool(a) if a.shape == () else a
+    return obs
+
   def state(self):
+    """environment.py:128-134: {'sprites': [...], 'global_state': {'success': ..., 'metadata': ...}} -- the sprites as
+    `LiveSprite` handles on the device state (attributes read and, for shape / angle / scale, assigned like the reference's).
+    The structure-of-arrays state (x, y, step_count, ...) is `soa_state()`."""
+    global_state = {'success': self.success()}
+    if self._batched._metadata:  # pylint: disable=protected-access
+      global_state['metadata'] = self._batched._metadata  # pylint: disable=protected-access
+    return {'sprites': self.sprites, 'global_state': global_state}
+
+  def soa_state(self):
+    """Host copies of the live structure-of-arrays state (swb_get_state): x, y f64[1, S], n_sprites, step_count, ..."""
     return self._batched.state()
 
   @property
   def sprites(self):
     """The current episode's sprites (reference: `env.state()['sprites']`) as `sprite.LiveSprite` handles whose
     shape / angle / scale can be assigned like on the reference's Sprite (sprite.py:152-175)."""
+    self._ensure_started()
     return self._batched.sprites(0)
 
   def close(self):

@@ -57,6 +57,28 @@ class Sprite(object):
     return collections.OrderedDict((name, getattr(self, name)) for name in FACTOR_NAMES)
 
 
+_MAX_TRIES = int(1e6)       # sprite.py:35
+
+
+def point_in_centered_path(path, tx, ty):
+  """matplotlib `_path.h` point_in_path_impl (radius 0, closed polygon) for one point: crossing parity with the
+  comparisons and products in matplotlib's order, all float64 (numpy scalars: IEEE, no FMA)."""
+  path = np.asarray(path, dtype=np.float64)
+  n = len(path)
+  tx, ty = np.float64(tx), np.float64(ty)
+  inside = False
+  vx0, vy0 = path[0]
+  yflag0 = vy0 >= ty
+  for i in range(1, n + 1):
+    vx1, vy1 = path[i % n]
+    yflag1 = vy1 >= ty
+    if yflag0 != yflag1:
+      if (((vy1 - ty) * (vx0 - vx1)) >= ((vx1 - tx) * (vy0 - vy1))) == yflag1:
+        inside = not inside
+    yflag0, vx0, vy0 = yflag1, vx1, vy1
+  return bool(inside)
+
+
 class LiveSprite(object):
   """Sprite `index` of environment `env` of a running engine, in its current episode.
 
@@ -110,6 +132,35 @@ class LiveSprite(object):
   @scale.setter
   def scale(self, s):
     self._environment.set_sprite_attr(self._env, self._index, 'scale', s)
+
+  @property
+  def centered_path(self):
+    """f64[n, 2]: the sprite's centred path as the engine holds it (sprite.py:96-101; swb_get_sprite)."""
+    return self._read()['path']
+
+  @property
+  def out_of_frame(self):
+    """sprite.py:135-138."""
+    pos = self.position
+    return not (np.all(pos >= [0., 0.]) and np.all(pos <= [1., 1.]))
+
+  def contains_point(self, point):
+    """sprite.py:113-115 -> matplotlib Path.contains_point (radius 0): the even-odd rule of `_path.h` point_in_path on the
+    centred path, float64, in matplotlib's operation order (the hit-test the cover kernel's `contains_point_wave` and the
+    oracle's `point_in_centered_path` restate)."""
+    t = np.asarray(point, dtype=np.float64) - self.position
+    return point_in_centered_path(self.centered_path, t[0], t[1])
+
+  def sample_contained_position(self):
+    """sprite.py:117-126: rejection sampling in the centred path's bounding box, consuming numpy's global stream exactly
+    as the reference does (one `np.random.uniform(low, high)` pair per try)."""
+    path, pos = self.centered_path, self.position
+    low, high = np.min(path, axis=0), np.max(path, axis=0)
+    for _ in range(_MAX_TRIES):
+      sample = pos + np.random.uniform(low, high)
+      if point_in_centered_path(path, sample[0] - pos[0], sample[1] - pos[1]):
+        return sample
+    raise ValueError('max_tries exceeded. There is almost surely an error in the SpriteWorld library code.')
 
   @property
   def vertices(self):

@@ -40,6 +40,15 @@ def _rewrite(text, name):
   text, n = re.subn(r'using cptr = const T __attribute__\(\(address_space\(4\)\)\)\*;', 'using cptr = const T*;   /* emu */', text)
   assert n == 1, 'constant address space alias not found'
   assert 'asm(' not in text.replace('asm("")', ''), 'an inline-assembly statement is left'
+  # bounds checks on the hand-off lists (counted by emu_violations(), see emu_runtime.cc): a run record is read at a unit
+  # below the list's capacity -- the sentinel is the last unit a list can hold
+  text = text.replace('#define SWB_WAVE 64', '#define SWB_WAVE 64\nextern "C" void emu_check(int ok);', 1)
+  anchor = 'rec = *reinterpret_cast<cptr<swb_u4>>(runs + uo);'
+  assert text.count(anchor) == 2, anchor
+  text = text.replace(anchor, anchor + ' emu_check(uo < 8u * (uint32_t)p.run_cap);')
+  anchor = 'hd = runs[2 * u]; s0 = runs[2 * u + 1];'
+  assert text.count(anchor) == 1, anchor
+  text = text.replace(anchor, 'emu_check(u < p.run_cap); ' + anchor)
   if os.environ.get('SWB_EMU_STATS'):
     text = _instrument(text)
   return text
@@ -88,6 +97,15 @@ def source_hash():
 
 
 def build(force=False):
+  """Builds (or reuses) the library; an exclusive file lock makes concurrent callers (pytest-xdist workers) wait for one build."""
+  import fcntl
+  os.makedirs(OUT_DIR, exist_ok=True)
+  with open(os.path.join(OUT_DIR, '.lock'), 'w') as lock:
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    return _build_locked(force)
+
+
+def _build_locked(force):
   stamp = LIB + '.hash'
   want = source_hash()
   if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == want:

@@ -241,6 +241,15 @@ extern "C" void emu_selftest_divergent_ballot() {
 }
 
 // Event counters of an instrumented build (SWB_EMU_STATS=1, tests/emu/build_emu.py): counted by lane 0 of a wave.
+// Bounds checks the emulated build adds to the kernel source (build_emu.py: reads of the hand-off lists): violations are
+// counted, not fatal, so that a test can assert on them.
+static long g_emu_violations;
+extern "C" void emu_check(int ok) { if (!ok) ++g_emu_violations; }
+extern "C" long emu_violations(int reset) {
+  const long v = g_emu_violations;
+  if (reset) g_emu_violations = 0;
+  return v;
+}
 static long g_emu_counters[32];
 extern "C" void emu_count(int counter, long amount) {
   if (emu::self().lane == 0 && counter >= 0 && counter < 32) g_emu_counters[counter] += amount;

@@ -177,18 +177,30 @@ def test_emulated_fill_kernel_for_narrow_images(monkeypatch, name, n_envs):
   _run(name, n_envs, 3, 1)
 
 
-def test_emulated_kernel_run_list_overflow_is_flagged(monkeypatch):
+@pytest.mark.parametrize('run_cap,bands,n_envs', [(24, 1, 4), (8, 4, 1), (12, 8, 3), (40, 2, 5)])
+def test_emulated_kernel_run_list_overflow_is_flagged(monkeypatch, run_cap, bands, n_envs):
   """A run list that does not fit its capacity (swb_params::run_cap; SWB_RUN_CAP lowers it) flags the environment
-  (SWB_ENV_ERR_SPAN_OVERFLOW) instead of writing past it."""
+  (SWB_ENV_ERR_SPAN_OVERFLOW) instead of writing past it -- and the second kernel never READS past it either: every band
+  of an overflowed list starts inside the written part (round-3 advice: with SWB_RUN_CAP=8, SWB_BANDS=4 a band header
+  pointed 114 units beyond an 8-unit list).  The emulated build counts run-record reads at or beyond the capacity."""
+  import ctypes as C
   from spriteworld_amd import _abi
-  monkeypatch.setenv('SWB_RUN_CAP', '24')
-  cfg, pool, sample = workloads.build('cluster_s5', 4, episodes_per_env=2, seed=0, anti_aliasing=5)
-  eng = _emu(cfg, pool)
-  rng = np.random.default_rng(0)
-  eng.step(sample(rng))
-  got = eng.outputs_host()
-  assert (got['error'] & _abi.ENV_ERR_SPAN_OVERFLOW).all()
-  eng.close()
+  monkeypatch.setenv('SWB_RUN_CAP', str(run_cap))
+  monkeypatch.setenv('SWB_BANDS', str(bands))
+  for aa, name in ((5, 'cluster_s5'), (1, 'wide_s4')):
+    if aa == 1:
+      monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')
+    cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=2, seed=0, anti_aliasing=aa)
+    eng = _emu(cfg, pool)
+    eng.lib.emu_violations.restype = C.c_long
+    eng.lib.emu_violations(1)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+      eng.step(sample(rng))
+    got = eng.outputs_host()
+    assert (got['error'] & _abi.ENV_ERR_SPAN_OVERFLOW).any()
+    assert eng.lib.emu_violations(1) == 0
+    eng.close()
 
 
 @pytest.mark.parametrize('name', _util.golden_cases())

@@ -7,11 +7,11 @@ config dict (its task / action-space / renderer / generator objects) goes unchan
 `spriteworld_amd.environment.Environment`, is lowered and stepped through the engine interface; the per-episode
 log lines (success, mean reward) and every time step must be identical.
 
-This container has no GPU, so the engine behind the interface is (a) tests/_fake_engine.py, the CPU oracle with the
-engine's method surface, and (b) tests/_emu_engine.py, the library's own sources -- C-ABI host side and the fused step
-kernel -- compiled for the host and executed lane by lane (tests/emu).  The hipcc build of the same sources is compared
-with the oracle bit for bit by the `-m gpu` tests; /root/reference does not exist on the GPU box, so reference and GPU
-cannot meet in one process anywhere.
+Three engines behind the interface: (a) tests/_fake_engine.py, the CPU oracle with the engine's method surface, and
+(b) tests/_emu_engine.py, the library's own sources -- C-ABI host side and kernels -- compiled for the host and executed
+lane by lane (tests/emu), both in the GPU-less build container; (c) `hip` (`-m gpu`): the product itself --
+`spriteworld_amd.engine.Engine`, libswb.so on the MI355X -- driven by the unmodified script on the GPU node, where the
+reference is present as the sourceless bytecode of `oracle/_ref` (oracle/stage_ref.py): BASELINE configs[0] end to end.
 """
 import copy
 import importlib
@@ -24,7 +24,8 @@ import pytest
 
 from oracle import ref_harness
 
-pytestmark = pytest.mark.skipif(not ref_harness.reference_available(), reason='reference tree not present')
+pytestmark = pytest.mark.skipif(not ref_harness.reference_available(),
+                                reason='neither /root/reference nor oracle/_ref (python oracle/stage_ref.py) present')
 
 CONFIG = 'spriteworld.configs.cobra.goal_finding_new_position'
 N_EPISODES = 6
@@ -96,18 +97,20 @@ def _run_main(monkeypatch, run_loop, episodes, use_dropin, steps):
   return handler.lines
 
 
-@pytest.mark.parametrize('backend', ['oracle', 'emulated_kernel'])
+@pytest.mark.parametrize('backend', ['oracle', 'emulated_kernel', pytest.param('hip', marks=pytest.mark.gpu)])
 def test_example_run_loop_main_drives_the_dropin(monkeypatch, backend):
   ref_harness.load_reference()
   from spriteworld_amd import environment as amd_environment
   run_loop = importlib.import_module('example_run_loop')
   if backend == 'oracle':
     from tests import _fake_engine
-    engine_class = _fake_engine.FakeEngine
-  else:       # the kernel source itself, run lane by lane on the host (tests/emu)
+    monkeypatch.setattr(amd_environment._engine, 'Engine', _fake_engine.FakeEngine)
+  elif backend == 'emulated_kernel':       # the kernel source itself, run lane by lane on the host (tests/emu)
     from tests import _emu_engine
-    engine_class = _emu_engine.EmuTorchEngine
-  monkeypatch.setattr(amd_environment._engine, 'Engine', engine_class)
+    monkeypatch.setattr(amd_environment._engine, 'Engine', _emu_engine.EmuTorchEngine)
+  else:                                    # the product: engine.Engine -> libswb.so -> the HIP kernels
+    from spriteworld_amd import engine as real_engine
+    assert amd_environment._engine.Engine is real_engine.Engine
   np.random.seed(5)
   episodes = [importlib.import_module(CONFIG).get_config('train')['init_sprites']() for _ in range(N_EPISODES + 2)]
   ref_steps, our_steps = [], []

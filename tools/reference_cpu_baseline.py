@@ -8,14 +8,19 @@ with anti_aliasing 5 -- seeded np.random.seed(1000 + env index), stepped round-r
 np.random.RandomState(2000 + step).uniform(size=(ENVS, 4)) (every worker takes its rows).  Warm-up steps, then timed steps;
 aggregate and per-core env-steps/s go to stdout as one JSON object (commit it under profiles/).
 
-Runs only where /root/reference exists (the build container, which has no GPU): bench.py quotes the committed result beside
-the same-run C port (`cpu_baseline.reference_all_cores`).   usage: python tools/reference_cpu_baseline.py [ENVS] [STEPS] [WARMUP] [P]"""
+Runs wherever `oracle/ref_harness.py` finds the reference: /root/reference (the build container) or, on the GPU node, its
+sourceless bytecode under oracle/_ref (oracle/stage_ref.py).  bench.py runs this script as a child process (a fresh
+interpreter: no forking next to a HIP context) for its `cpu_baseline` block, kind "reference".  Every worker is ONE core:
+the BLAS / OpenMP pools of numpy and sklearn are pinned to one thread.
+usage: python tools/reference_cpu_baseline.py [ENVS] [STEPS] [WARMUP] [P]"""
 import json
-import multiprocessing as mp
 import os
-import platform
-import sys
-import time
+for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
+  os.environ[_v] = '1'                     # before numpy loads: a worker process is one core
+import multiprocessing as mp  # noqa: E402
+import platform  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -86,9 +91,13 @@ def main():
     cpu = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
   except (OSError, IndexError):
     pass
+  from oracle import ref_harness
   print(json.dumps({
-      'what': 'unmodified reference (/root/reference, Python + PIL + matplotlib + sklearn), headline scene of BASELINE configs[2]',
-      'where': 'build container (no GPU) -- NOT the GPU node', 'cpu': cpu, 'machine': platform.machine(),
+      'what': 'unmodified reference (Python + PIL + matplotlib + sklearn), headline scene of BASELINE configs[2]',
+      'reference_root': ref_harness.REFERENCE_ROOT, 'reference_kind': ref_harness.reference_kind(),
+      'third_party': ref_harness.third_party_versions(),
+      'where': os.environ.get('SWB_REF_WHERE', 'host ' + platform.node()), 'cpu': cpu, 'machine': platform.machine(),
+      'host_cpus': os.cpu_count(),
       'processes': nproc, 'envs': envs, 'timed_steps_per_env': steps, 'warmup_steps_per_env': warmup,
       'env_steps_per_s_all_cores': total / slowest, 'env_steps_per_s_per_core': total / slowest / nproc,
       'timed_seconds_slowest_worker': slowest, 'wall_seconds_incl_setup': wall, 'frame_checksum': sum(r[3] for r in res)}, indent=1))
