@@ -124,12 +124,14 @@ typedef void (*kernel_fn)(const swb_params);
 
 // cover kernel by canvas width (NW 32-pixel words per canvas row); resample kernel by the output rows a canvas
 // row can feed at once (VS)
-struct variant { int nw; kernel_fn fn, fn_ov; size_t lds_fixed, outrow_bytes; };
+struct variant { int nw; kernel_fn fn, fn_ov, fn_paint, fn_paint_ov; size_t lds_fixed, outrow_bytes; };
 
 template <int NW>
 variant make_variant() {
   const size_t outrow = 528;          // wave_lds::outrow is build_all_edges' scratch (132 dwords)
-  return {NW, swb_cover_kernel<NW>, swb_cover_kernel<NW, true>, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
+  kernel_fn paint = nullptr, paint_ov = nullptr;       // the builds that paint the frame themselves: canvases of up to 64 px only
+  if constexpr (NW == 2) { paint = swb_cover_kernel<NW, false, true>; paint_ov = swb_cover_kernel<NW, true, true>; }
+  return {NW, swb_cover_kernel<NW>, swb_cover_kernel<NW, true>, paint, paint_ov, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
 }
 
 const variant kVariants[] = {make_variant<2>(), make_variant<4>(), make_variant<5>(), make_variant<10>(), make_variant<20>()};
@@ -290,7 +292,8 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   p.outrow_bytes = (int32_t)v->outrow_bytes;
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
   // engines on which a sprite setter has been called run the build that reads the per-environment overrides
-  const kernel_fn fn = h->d_ov_flag ? v->fn_ov : v->fn;
+  const bool paint = h->p.AA == 1 && h->p.ncg == 1 && out && out->obs && !h->no_paint_in_cover && v->fn_paint;
+  const kernel_fn fn = paint ? (h->d_ov_flag ? v->fn_paint_ov : v->fn_paint) : (h->d_ov_flag ? v->fn_ov : v->fn);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // first launch, a new pool that shrank the LDS footprint (more waves resident), or the switch to the override build
@@ -319,7 +322,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   p.parity = h->launch_parity;
   p.cphase = h->launch_phase;
   // anti_aliasing = 1, one column group: the cover kernel paints the frame itself, there is no second kernel
-  p.paint_in_cover = (p.AA == 1 && p.ncg == 1 && p.obs && !h->no_paint_in_cover) ? 1 : 0;
+  p.paint_in_cover = paint ? 1 : 0;
   // environments in order of what their cover wave cost in the previous launch -- if that launch filed them all
   // (and the launch is more than one round of cover waves but not many: one round needs no order, and from about a dozen
   // rounds on the plain order was measured 1.6 % faster)
