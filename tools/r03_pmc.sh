@@ -18,6 +18,8 @@ for s in "$@"; do
     sqc) pmc sqc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_REQ SQC_ICACHE_REQ SQC_ICACHE_MISSES ;;
     write) pmc write WRITE_SIZE ;;
     fetch) pmc fetch FETCH_SIZE ;;
+    lds) pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES ;;
+    misc) pmc misc SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_WAVE_CYCLES SQ_WAVES ;;
     wait) pmc wait SQ_WAIT_INST_LDS SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_WR SQ_IFETCH SQ_WAVE_CYCLES SQ_WAVES ;;
   esac
 done
