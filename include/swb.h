@@ -354,8 +354,6 @@ typedef struct swb_variant_info {
   int32_t run_cap;            /* capacity of a run list (8-byte units per environment and column group) */
   int32_t paint_in_cover;     /* 1: anti_aliasing = 1 and an image of up to 64 columns -- the cover kernel writes the frame
                                * itself and no second kernel is launched */
-  int32_t state_lds_bytes_per_wave; /* state kernel (P0, P1), = per environment */
-  int32_t state_waves_per_simd;     /* register budget the state kernel was compiled for */
 } swb_variant_info;
 int swb_variant(swb_handle h, swb_variant_info* out);
 const char* swb_build_id(void);
@@ -364,11 +362,9 @@ const char* swb_build_id(void);
  * while enabled; swb_step_time_ms returns (total ms, launches) since enable. */
 int swb_timing_enable(swb_handle h, int32_t enable);
 int swb_step_time_ms(swb_handle h, double* total_ms, int64_t* launches);
-/* The same interval split at the event before the last kernel of a step: state + cover (state, geometry,
+/* The same interval split at the event between the two kernels of a step: cover (state, geometry,
  * coverage -> run lists) and resample / fill (run lists -> frames). */
 int swb_kernel_times_ms(swb_handle h, double* cover_ms, double* resample_ms, int64_t* launches);
-/* ... and at the event between the state kernel (P0 state, P1 geometry) and the cover kernel (P2 coverage) too. */
-int swb_kernel_times3_ms(swb_handle h, double* state_ms, double* cover_ms, double* second_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,6 @@ EXPORTS = (
     'swb_upload_resample', 'swb_set_pool', 'swb_sample_pool', 'swb_resample_pool', 'swb_get_pool', 'swb_reset_all', 'swb_step', 'swb_render', 'swb_factors',
     'swb_get_state', 'swb_set_positions', 'swb_variant', 'swb_build_id', 'swb_timing_enable', 'swb_step_time_ms',
     'swb_set_sprite_attr', 'swb_get_sprite', 'swb_sprite_path_op', 'swb_kernel_times_ms', 'swb_get_env_state',
-    'swb_kernel_times3_ms',
 )
 
 _lib = None
@@ -71,7 +70,6 @@ def load():
   lib.swb_timing_enable.argtypes = [C.c_void_p, C.c_int32]
   lib.swb_step_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
   lib.swb_kernel_times_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-  lib.swb_kernel_times3_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
   _lib = lib
   return lib
 

@@ -21,6 +21,7 @@
 
 // the cover kernels of canvases wider than 320 px are instantiated in swb_wide.hip (other scheduler flags)
 extern template __global__ void swb_cover_kernel<20, false>(const swb_params);
+extern template __global__ void swb_cover_kernel<20, true>(const swb_params);
 
 namespace {
 
@@ -98,8 +99,6 @@ struct swb_engine {
   int launch_parity = 0;
   // hand-off cover -> resample
   uint32_t *d_runs = nullptr, *d_rhdr = nullptr;
-  uint32_t* d_geo = nullptr;         // hand-off state kernel -> cover kernel (swb_params::geo)
-  int geo_stride = 0;
   int32_t *d_band_y0 = nullptr, *d_band_first = nullptr, *d_band_lo = nullptr, *d_cg_lo = nullptr, *d_cg_hi = nullptr;
   uint32_t* d_v_break = nullptr;
   // live sprite overrides (swb_set_sprite_attr), allocated at the first call
@@ -109,13 +108,13 @@ struct swb_engine {
   int8_t* d_ov_label = nullptr;
   // timing
   bool timing = false;
-  struct step_events { hipEvent_t e0, es, e1, e2; };  // before state, state | cover, cover | resample / fill, after it
+  struct step_events { hipEvent_t e0, e1, e2; };     // before cover, between the kernels, after resample / fill
   std::vector<step_events> events;
   std::vector<step_events> event_pool;               // events of flushed steps, reused (no hipEventCreate per step)
   // read once at swb_create (never per launch): the device's compute units and the test / A-B switches of the environment
   int cus = 0;
   bool no_paint_in_cover = false, force_cover_order = false;
-  double timed_ms = 0.0, timed_cover_ms = 0.0, timed_state_ms = 0.0;
+  double timed_ms = 0.0, timed_cover_ms = 0.0;
   int64_t timed_launches = 0;
 };
 
@@ -125,13 +124,14 @@ typedef void (*kernel_fn)(const swb_params);
 
 // cover kernel by canvas width (NW 32-pixel words per canvas row); resample kernel by the output rows a canvas
 // row can feed at once (VS)
-struct variant { int nw; kernel_fn fn, fn_paint; size_t lds_fixed; };
+struct variant { int nw; kernel_fn fn, fn_ov, fn_paint, fn_paint_ov; size_t lds_fixed, outrow_bytes; };
 
 template <int NW>
 variant make_variant() {
-  kernel_fn paint = nullptr;          // the build that paints the frame itself: canvases of up to 64 px only
-  if constexpr (NW == 2) paint = swb_cover_kernel<NW, true>;
-  return {NW, swb_cover_kernel<NW>, paint, (sizeof(wave_lds<NW>) + 15) & ~(size_t)15};
+  const size_t outrow = 528;          // wave_lds::outrow is build_all_edges' scratch (132 dwords)
+  kernel_fn paint = nullptr, paint_ov = nullptr;       // the builds that paint the frame themselves: canvases of up to 64 px only
+  if constexpr (NW == 2) { paint = swb_cover_kernel<NW, false, true>; paint_ov = swb_cover_kernel<NW, true, true>; }
+  return {NW, swb_cover_kernel<NW>, swb_cover_kernel<NW, true>, paint, paint_ov, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
 }
 
 const variant kVariants[] = {make_variant<2>(), make_variant<4>(), make_variant<5>(), make_variant<10>(), make_variant<20>()};
@@ -149,14 +149,15 @@ kernel_fn pick_resample(int AA, int vslots, int* vs_out) {
   return swb_resample_kernel<8>;
 }
 
-// LDS bytes of one wave (= one environment) of the cover kernel: row masks + span lists ...
-size_t lds_per_wave(const swb_engine* h, const variant* v) {
-  return (v->lds_fixed + (size_t)h->p.max_spans * SWB_WAVE * 4 + 15) & ~(size_t)15;
-}
-// ... and of the state kernel: sprite records + P1b scratch + edge records (first the centred paths) + task scratch
-size_t state_lds_per_wave(const swb_engine* h) {
-  return (((sizeof(state_lds) + 15) & ~(size_t)15) + (((size_t)h->p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
-          sizeof(task_scratch) + 15) & ~(size_t)15;
+// LDS bytes of one wave (= one environment) of the cover kernel: wave_lds + edge records + span lists.  The
+// centred paths (16 B per vertex) borrow the idle mask arrays, or the edge records' storage.
+size_t lds_per_wave(const swb_engine* h, const variant* v, int* cpath_in_masks) {
+  const swb_params& p = h->p;
+  const size_t cpath_bytes = (size_t)p.max_edges * 16;
+  const int in_masks = (2 * (size_t)SWB_NWA(v->nw) * SWB_WAVE * 4 >= cpath_bytes) ? 1 : 0;
+  if (cpath_in_masks) *cpath_in_masks = in_masks;
+  return (v->lds_fixed + (((size_t)p.max_edges * sizeof(edge_rec) + 15) & ~(size_t)15) +
+          (size_t)p.max_spans * SWB_WAVE * 4 + 15) & ~(size_t)15;
 }
 
 // Overflow slots for the span lists of the cover kernel: one per wave that can be resident at once (occupancy of
@@ -247,13 +248,11 @@ int ensure_handoff_tables(swb_engine* h) {
 int flush_timing(swb_engine* h) {
   for (auto& ev : h->events) {
     HIP_TRY(hipEventSynchronize(ev.e2));
-    float ms = 0.f, ms_cover = 0.f, ms_state = 0.f;
+    float ms = 0.f, ms_cover = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e2));
     HIP_TRY(hipEventElapsedTime(&ms_cover, ev.e0, ev.e1));
-    HIP_TRY(hipEventElapsedTime(&ms_state, ev.e0, ev.es));
     h->timed_ms += ms;
     h->timed_cover_ms += ms_cover;
-    h->timed_state_ms += ms_state;
     h->timed_launches += 1;
     h->event_pool.push_back(ev);
   }
@@ -286,29 +285,17 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   p.error = out ? out->error : nullptr;
   p.render_only = render_only;
   if (!render_only && actions == nullptr) return fail(SWB_ERR_INVALID, "actions is NULL");
-  const size_t lds = lds_per_wave(h, v), lds0 = state_lds_per_wave(h);
+  int cpath_in_masks = 0;
+  const size_t lds = lds_per_wave(h, v, &cpath_in_masks);
+  p.cpath_in_masks = cpath_in_masks;
   p.lds_per_wave = (int32_t)lds;
-  p.state_lds = (int32_t)lds0;
-  p.nw = v->nw;
-  if (lds > 160 * 1024 || lds0 > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", std::max(lds, lds0));
-  // engines on which a sprite setter has been called run the state kernel that reads the per-environment overrides
-  const kernel_fn fn0 = h->d_ov_flag ? swb_state_kernel<true> : swb_state_kernel<false>;
+  p.outrow_bytes = (int32_t)v->outrow_bytes;
+  if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
+  // engines on which a sprite setter has been called run the build that reads the per-environment overrides
   const bool paint = h->p.AA == 1 && h->p.ncg == 1 && out && out->obs && !h->no_paint_in_cover && v->fn_paint;
-  const kernel_fn fn = paint ? v->fn_paint : v->fn;
+  const kernel_fn fn = paint ? (h->d_ov_flag ? v->fn_paint_ov : v->fn_paint) : (h->d_ov_flag ? v->fn_ov : v->fn);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (lds0 > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
-  // hand-off state -> cover: header + edge records per environment (grows with the pool's largest episode)
-  {
-    const int stride = (SWB_GEO_HDR_DWORDS + 4 * p.max_edges + 15) & ~15;
-    if (!h->d_geo || stride > h->geo_stride) {
-      if (h->d_geo) HIP_TRY(hipDeviceSynchronize());
-      if (upload(&h->d_geo, (const uint32_t*)nullptr, (size_t)p.N * stride)) return SWB_ERR_HIP;
-      h->geo_stride = stride;
-    }
-    p.geo = h->d_geo; p.geo_stride = h->geo_stride;
-  }
   // first launch, a new pool that shrank the LDS footprint (more waves resident), or the switch to the override build
   if (!h->d_ovf || (int)lds < h->ovf_lds_bytes || fn != h->ovf_fn) {
     if (h->d_ovf) {
@@ -321,12 +308,11 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
     h->ovf_fn = fn;
     p.ovf = h->p.ovf; p.ovf_bitmap = h->p.ovf_bitmap; p.ovf_slots = h->p.ovf_slots;
   }
-  swb_engine::step_events ev = {nullptr, nullptr, nullptr, nullptr};
+  swb_engine::step_events ev = {nullptr, nullptr, nullptr};
   if (h->timing) {
     if (!h->event_pool.empty()) { ev = h->event_pool.back(); h->event_pool.pop_back(); }
     else {
       HIP_TRY(hipEventCreate(&ev.e0));
-      HIP_TRY(hipEventCreate(&ev.es));
       HIP_TRY(hipEventCreate(&ev.e1));
       HIP_TRY(hipEventCreate(&ev.e2));
     }
@@ -346,9 +332,6 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
     if (p.N > 2 * slots) p.prio_levels &= ~2;          // (cover waves' priorities: measured +1.3 % at three rounds of waves)
   }
   // (cost-ordered: block b serves rank b / 8 of shard b % 8; a shard holds up to cost_cap environments)
-  auto launch_state = [&](int e0, int e1) {
-    hipLaunchKernelGGL(fn0, dim3(e1 - e0), dim3(SWB_WAVE), lds0, stream, p);
-  };
   auto launch_cover = [&](int e0, int e1) {
     hipLaunchKernelGGL(fn, dim3(e1 - e0), dim3(SWB_WAVE), lds, stream, p);
   };
@@ -358,10 +341,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
     const dim3 grid(blocks_x, p.nbands, p.cost_cnt ? 1 : p.ncg);      // (cost-ordered: a list entry names its column group)
     hipLaunchKernelGGL(fn2, grid, dim3(SWB_WAVE * SWB_RS_WAVES_PER_BLOCK), lds2, st, p);
   };
-  launch_state(0, c.n_envs);
-  HIP_TRY(hipGetLastError());
-  if (h->timing) HIP_TRY(hipEventRecord(ev.es, stream));
-  if (p.obs) launch_cover(0, c.n_envs);                 // (a step without a frame is the state kernel alone)
+  launch_cover(0, c.n_envs);
   HIP_TRY(hipGetLastError());
   if (h->timing && !p.paint_in_cover) HIP_TRY(hipEventRecord(ev.e1, stream));
   if (p.obs && !p.paint_in_cover) launch_resample(0, c.n_envs, stream);
@@ -369,7 +349,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   if (!p.obs && p.cost_cnt)       // no second kernel to clear the next launch's bucket counters (kind 0; the cover kernel keeps kind 1)
     HIP_TRY(hipMemsetAsync(h->d_cost_cnt + (size_t)(p.parity ^ 1) * SWB_COST_SET, 0, SWB_COST_SET * sizeof(uint32_t), stream));
   h->cover_lists_filed = p.obs && p.ccost_list;
-  if (p.obs) h->launch_phase = (h->launch_phase + 1) % 3;      // (a launch without a cover kernel files and clears nothing: its phase is not used up)
+  h->launch_phase = (h->launch_phase + 1) % 3;
   h->launch_parity ^= 1;
   if (h->timing) {
     if (p.paint_in_cover) HIP_TRY(hipEventRecord(ev.e1, stream));      // (no second kernel: the whole step is the cover kernel)
@@ -510,13 +490,13 @@ int swb_destroy(swb_handle h) {
   if (!h) return SWB_OK;
   (void)hipSetDevice(h->device);
   for (auto* list : {&h->events, &h->event_pool})
-    for (auto& ev : *list) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.es); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
+    for (auto& ev : *list) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
   void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
                   h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler,
                   h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label,
-                  h->d_cost_cnt, h->d_cost_list, h->d_ccost_list, h->d_runs, h->d_rhdr, h->d_geo, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
+                  h->d_cost_cnt, h->d_cost_list, h->d_ccost_list, h->d_runs, h->d_rhdr, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;
@@ -1139,10 +1119,8 @@ int swb_variant(swb_handle h, swb_variant_info* out) {
   int vs = 0;
   (void)pick_resample(h->p.AA, h->vslots, &vs);
   out->nw = v->nw; out->ncol = 1; out->vs = vs;
-  out->lds_bytes_per_wave = (int32_t)lds_per_wave(h, v);
+  out->lds_bytes_per_wave = (int32_t)lds_per_wave(h, v, nullptr);
   out->waves_per_simd = v->nw <= 10 ? SWB_COVER_WAVES_PER_SIMD : SWB_COVER_WAVES_PER_SIMD_WIDE;
-  out->state_lds_bytes_per_wave = (int32_t)state_lds_per_wave(h);
-  out->state_waves_per_simd = SWB_STATE_WAVES_PER_SIMD;
   out->resample_waves_per_simd = SWB_RS_WAVES_PER_SIMD;
   out->n_bands = h->p.nbands ? h->p.nbands : h->nbands;
   out->n_column_groups = (h->p.Wo + 63) / 64;
@@ -1163,7 +1141,6 @@ int swb_timing_enable(swb_handle h, int32_t enable) {
   h->timing = enable != 0;
   h->timed_ms = 0.0;
   h->timed_cover_ms = 0.0;
-  h->timed_state_ms = 0.0;
   h->timed_launches = 0;
   return SWB_OK;
 }
@@ -1183,17 +1160,6 @@ int swb_kernel_times_ms(swb_handle h, double* cover_ms, double* resample_ms, int
   if (flush_timing(h)) return SWB_ERR_HIP;
   if (cover_ms) *cover_ms = h->timed_cover_ms;
   if (resample_ms) *resample_ms = h->timed_ms - h->timed_cover_ms;
-  if (launches) *launches = h->timed_launches;
-  return SWB_OK;
-}
-
-int swb_kernel_times3_ms(swb_handle h, double* state_ms, double* cover_ms, double* second_ms, int64_t* launches) {
-  if (!h) return fail(SWB_ERR_INVALID, "null handle");
-  HIP_TRY(hipSetDevice(h->device));
-  if (flush_timing(h)) return SWB_ERR_HIP;
-  if (state_ms) *state_ms = h->timed_state_ms;
-  if (cover_ms) *cover_ms = h->timed_cover_ms - h->timed_state_ms;
-  if (second_ms) *second_ms = h->timed_ms - h->timed_cover_ms;
   if (launches) *launches = h->timed_launches;
   return SWB_OK;
 }

@@ -7,3 +7,5 @@
 #include "swb_pow.hip.inc"
 
 template __global__ void swb_cover_kernel<20, false>(const swb_params);
+// ... and the build with live sprite overrides (swb_set_sprite_attr)
+template __global__ void swb_cover_kernel<20, true>(const swb_params);

@@ -196,8 +196,7 @@ class Engine(object):
     info = _abi.SwbVariantInfo()
     _lib.check(self.lib.swb_variant(self._h, C.byref(info)))
     d = {k: getattr(info, k) for k, _ in _abi.SwbVariantInfo._fields_}
-    d['state_kernel'] = 'swb_state_kernel'
-    d['cover_kernel'] = 'swb_cover_kernel<%d%s>' % (info.nw, ', PAINT' if info.paint_in_cover else '')
+    d['cover_kernel'] = 'swb_cover_kernel<%d>' % info.nw
     d['kernel'] = ('swb_resample_kernel<%d>' % info.vs if info.vs else
                    ('none (the cover kernel paints the frame)' if info.paint_in_cover else 'swb_fill_kernel'))
     d['build_id'] = self.lib.swb_build_id().decode()
@@ -212,13 +211,7 @@ class Engine(object):
     return ms.value, n.value
 
   def kernel_times_ms(self):
-    """(state + cover ms, resample / fill ms, launches) since timing(True): the step interval split before its last kernel."""
+    """(cover ms, resample / fill ms, launches) since timing(True): the step interval split between its two kernels."""
     a, b, n = C.c_double(0.0), C.c_double(0.0), C.c_int64(0)
     _lib.check(self.lib.swb_kernel_times_ms(self._h, C.byref(a), C.byref(b), C.byref(n)))
     return a.value, b.value, n.value
-
-  def kernel_times3_ms(self):
-    """(state ms, cover ms, resample / fill ms, launches) since timing(True): every kernel of a step on its own."""
-    a, b, c, n = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_int64(0)
-    _lib.check(self.lib.swb_kernel_times3_ms(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
-    return a.value, b.value, c.value, n.value

@@ -30,16 +30,11 @@ def run(name, n, aa, bands, steps=40, warmup=10):
   torch.cuda.synchronize()
   tot, k = eng.step_time_ms()
   a, b, _ = eng.kernel_times_ms()
-  try:
-    s0, s1, _, _ = eng.kernel_times3_ms()
-    split = ' (state %.4f + cover %.4f)' % (s0 / k, s1 / k)
-  except AttributeError:                      # a build from before the state / cover split
-    split = ''
   v = eng.variant()
   err = int(eng.error.max().item())
   eng.close()
-  print('%-14s N=%-6d AA=%d bands=%d  step %.4f ms  cover %.4f  %s %.4f   (%.1f M env-steps/s, errors %d)%s' %
-        (name, n, aa, v['n_bands'], tot / k, a / k, v['kernel'], b / k, n / (tot / k) / 1e3, err, split), flush=True)
+  print('%-14s N=%-6d AA=%d bands=%d  step %.4f ms  cover %.4f  %s %.4f   (%.1f M env-steps/s, errors %d)' %
+        (name, n, aa, v['n_bands'], tot / k, a / k, v['kernel'], b / k, n / (tot / k) / 1e3, err), flush=True)
 
 
 if __name__ == '__main__':
