@@ -19,7 +19,7 @@ roofline:     a step is two kernels on one stream (cover: state + geometry + cov
               dominant one (resample, which writes the frames) the rate of its own bytes.  `kernel`, `metric`
               and `config` are derived from what ran (swb_variant / the lowered config); `traffic` and
               `instructions` come from the committed PMC passes of exactly this build
-              (profiles/r03_counters.json, keyed by the library's build id) or are null.
+              (profiles/rNN_counters.json, keyed by the library's build id) or are null.
 cpu_baseline: kind "reference" -- the UNMODIFIED reference (Python + PIL + matplotlib + sklearn; on the GPU node the
               sourceless bytecode of /root/reference under oracle/_ref, oracle/stage_ref.py) stepping a bounded sample
               of the headline scene on ALL host cores of rank 0 in this same run (tools/reference_cpu_baseline.py:
@@ -59,19 +59,19 @@ VALU_CYCLES_PER_INST = 4.24      # profiles/r02_ubench_valu.md + SQ_ACTIVE_INST_
 
 
 def profiled_counters(workload, envs, aa, build_id):
-  """PMC figures of the committed rocprofv3 passes (profiles/r03_counters.json) for this exact build and workload.
+  """PMC figures of the committed rocprofv3 passes (profiles/rNN_counters.json, newest round first) for this exact build and
+  workload.
 
-  bench.py cannot collect PMC counters itself.  The file records the build id (content hash of the kernel sources)
-  the passes ran on; for any other build, workload or batch the figures are stale and None is returned."""
-  path = os.path.join(ROOT, 'profiles', 'r03_counters.json')
-  if not os.path.exists(path):
-    return None
-  with open(path) as f:
-    data = json.load(f)
-  for rec in data.get('records', []):
-    if (rec['build_id'] == build_id and rec['workload'] == workload and rec['envs'] == envs and
-        rec['anti_aliasing'] == aa):
-      return rec
+  bench.py cannot collect PMC counters itself.  A file records the build id (content hash of the kernel sources) its passes
+  ran on; for any other build, workload or batch the figures are stale and None is returned."""
+  import glob
+  for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_counters.json')), reverse=True):
+    with open(path) as f:
+      data = json.load(f)
+    for rec in data.get('records', []):
+      if (rec['build_id'] == build_id and rec['workload'] == workload and rec['envs'] == envs and
+          rec['anti_aliasing'] == aa):
+        return rec
   return None
 
 
@@ -347,7 +347,7 @@ def assemble_line(args, res, elapsed):
   if counters:
     # instruction side (SURVEY 8d asks for both): the step is bound by instruction issue, not by HBM.  Per environment:
     # what the two kernels retire, the time that alone takes on a SIMD's vector ALU, and the cost model's minimum for
-    # the resample kernel from exact event counts (tools/r03_assemble.py, tools/emu_stats.py)
+    # the resample kernel from exact event counts (tools/assemble_evidence.py, tools/emu_stats.py)
     valu = counters['insts_valu_per_env']
     envs_per_simd = args.envs_per_gpu / 1024.0
     roofline['instructions'] = {

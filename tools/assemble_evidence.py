@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""Turns what tools/r03_final.sh left under gpurun_out/TAG into the committed evidence under profiles/:
-  r03_rocprofv3_summary_{default,aa1,embodied_s12_128}.md   kernel trace + the PMC tables of both kernels
-  r03_counters.json                                         what bench.py quotes, keyed by the build id of the run
-  r03_bench_default.json, r03_wave_timeline.md
-usage: python tools/r03_assemble.py gpurun_out/TAG"""
+"""Turns what tools/final_evidence.sh left under gpurun_out/TAG into the committed evidence under profiles/ (ROUND = r04 ...):
+  ROUND_rocprofv3_summary_{default,aa1,embodied_s12_128}.md   kernel trace + the PMC tables of both kernels
+  ROUND_counters.json                                         what bench.py quotes, keyed by the build id of the run
+  ROUND_bench_default.json, ROUND_bench_driver_cmd.json, ROUND_launch_convergence.json
+usage: python tools/assemble_evidence.py ROUND gpurun_out/TAG"""
 import json
 import os
 import subprocess
@@ -16,7 +16,7 @@ RUNS = (('default', 'cluster_s5', 5), ('aa1', 'cluster_s5', 1), ('embodied_s12_1
 
 def load_pmc(d):
   out = {}
-  for name in ('insts', 'active', 'write', 'fetch'):
+  for name in ('insts', 'active', 'write', 'fetch', 'wait', 'lds'):
     path = os.path.join(d, 'pmc_%s.json' % name)
     if os.path.exists(path) and os.path.getsize(path) > 2:
       for kernel, c in json.load(open(path)).items():
@@ -40,7 +40,7 @@ def model_min(workload, aa):
 
 
 def main():
-  src = sys.argv[1]
+  rnd, src = sys.argv[1], sys.argv[2]
   records = []
   for tag, workload, aa in RUNS:
     d = os.path.join(src, tag)
@@ -56,7 +56,7 @@ def main():
         by[role] = dict(c, kernel=kernel)
     lines = open(os.path.join(d, 'summary.md')).read().rstrip().split('\n') if os.path.exists(os.path.join(d, 'summary.md')) else []
     if by:
-      lines += ['', '## Counters per kernel (rocprofv3 --pmc, one process per counter set, tools/r03_pmc.sh; averages per dispatch, '
+      lines += ['', '## Counters per kernel (rocprofv3 --pmc, one process per counter set, tools/pmc_sets.sh; averages per dispatch, '
                 'per environment where divided)', '',
                 '| kernel | waves | VALU / env | SALU / env | LDS / env | SMEM / env | wave quad-cycles / wave | vector ALU busy (SQ_ACTIVE_INST_VALU x 4 cycles '
                 '/ 1024 SIMDs / 2.4 GHz / kernel time) | WRITE_SIZE MB | 2 x FETCH_SIZE MB |', '|---|---|---|---|---|---|---|---|---|---|']
@@ -88,7 +88,7 @@ def main():
         'fetch_correction': 2.0, 'algorithmic_bytes_per_launch': a_bytes,
         'resample_valu_model_min_per_env': model, 'events_per_env': events,
         'kernel_ms_unprofiled': bench['roofline']['kernel_ms'], 'kernels_ms_unprofiled': {k['name']: k['ms'] for k in bench['roofline']['kernels']},
-        'source': 'profiles/r03_rocprofv3_summary_%s.md (rocprofv3 --pmc, one pass per counter set, 10 measured steps each; SQ cycle counters in '
+        'source': 'profiles/' + rnd + '_rocprofv3_summary_%s.md (rocprofv3 --pmc, one pass per counter set, 10 measured steps each; SQ cycle counters in '
                   'quad-cycles; FETCH_SIZE doubled per MI355X_MICROARCH.md; traffic = both kernels of a step)' % tag,
     }
     if by:
@@ -103,12 +103,20 @@ def main():
         lines += ['', 'Resample kernel, vector instructions per environment: measured %.0f, cost-model minimum %.0f (x %.2f; tools/emu_stats.py).' % (
             rec['insts_valu_per_env_by_kernel'].get('resample', 0), model, rec['insts_valu_per_env_by_kernel'].get('resample', 0) / model)]
     if lines:
-      open(os.path.join(ROOT, 'profiles', 'r03_rocprofv3_summary_%s.md' % tag), 'w').write('\n'.join(lines) + '\n')
+      open(os.path.join(ROOT, 'profiles', '%s_rocprofv3_summary_%s.md' % (rnd, tag)), 'w').write('\n'.join(lines) + '\n')
   if records:
-    json.dump({'records': records}, open(os.path.join(ROOT, 'profiles', 'r03_counters.json'), 'w'), indent=1)
-  b = os.path.join(src, 'bench_default.json')
-  if os.path.exists(b) and os.path.getsize(b) > 10:
-    open(os.path.join(ROOT, 'profiles', 'r03_bench_default.json'), 'w').write(open(b).read())
+    json.dump({'records': records}, open(os.path.join(ROOT, 'profiles', rnd + '_counters.json'), 'w'), indent=1)
+  for name in ('bench_default', 'bench_driver_cmd'):
+    b = os.path.join(src, name + '.json')
+    if os.path.exists(b) and os.path.getsize(b) > 10:
+      open(os.path.join(ROOT, 'profiles', '%s_%s.json' % (rnd, name)), 'w').write(open(b).read())
+  conv = {}
+  for name in ('convergence_headline', 'convergence_embodied'):
+    b = os.path.join(src, name + '.json')
+    if os.path.exists(b) and os.path.getsize(b) > 10:
+      conv[name] = json.load(open(b))
+  if conv:
+    json.dump(conv, open(os.path.join(ROOT, 'profiles', rnd + '_launch_convergence.json'), 'w'), indent=1)
   print('records:', [(r['workload'], r['anti_aliasing'], r['build_id']) for r in records])
 
 

@@ -40,6 +40,26 @@ def main():
     tail = float(np.mean(step_ms[-16:]))
     out['engines'].append({'trial': trial, 'step_ms': step_ms, 'cover_ms': cover_ms, 'mean_last_16': tail,
                            'first_launch_within_1pct': next((i for i in range(launches) if max(step_ms[i:i + 4]) <= 1.01 * tail), None)})
+  # control: a fixed, compute-bound library kernel (fp32 matmul 2048^3) timed the same way after one second of idling -- if its
+  # launches speed up over the same tens of milliseconds, what converges is the device (clocks), not the engine's dispatch
+  import time
+  a = torch.randn(2048, 2048, device='cuda')
+  b = torch.randn(2048, 2048, device='cuda')
+  torch.mm(a, b)
+  torch.cuda.synchronize()
+  control = []
+  for trial in range(2):
+    time.sleep(1.0)
+    ms = []
+    for i in range(launches):
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      torch.mm(a, b)
+      e1.record()
+      torch.cuda.synchronize()
+      ms.append(round(e0.elapsed_time(e1), 5))
+    control.append({'trial': trial, 'matmul_ms': ms, 'mean_first_8': float(np.mean(ms[:8])), 'mean_last_16': float(np.mean(ms[-16:]))})
+  out['control_fp32_matmul_2048'] = control
   print(json.dumps(out))
 
 

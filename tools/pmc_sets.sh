@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over one workload (each counter set in its own rocprofv3 process).  usage: tools/r03_pmc.sh TAG WORKLOAD N AA [sets...]
+# PMC passes over one workload (each counter set in its own rocprofv3 process).  usage: tools/pmc_sets.sh TAG WORKLOAD N AA [sets...]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; W=$2; N=$3; AA=$4; shift 4

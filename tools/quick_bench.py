@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel times of a step (HIP events on the launch stream: whole step, cover kernel, resample / fill kernel) for a
-list of workloads.  usage: python tools/r03_quick.py WORKLOAD:N_ENVS:AA[:BANDS] ...   (BANDS -> SWB_BANDS)"""
+list of workloads.  usage: python tools/quick_bench.py WORKLOAD:N_ENVS:AA[:BANDS] ...   (BANDS -> SWB_BANDS)"""
 import os
 import sys
 

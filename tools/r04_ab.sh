@@ -19,7 +19,7 @@ for k in sorted(d):
 PY
 if [ -n "$PHASES" ]; then rm -f $OUT/phases.md; python tools/phase_profile.py $OUT/phases.md cluster_s5:5 cluster_s5:1 embodied_s12:5 2>&1 | tail -4; fi
 if [ -n "$PMC" ]; then
-  bash tools/r03_pmc.sh $TAG/pmc_headline cluster_s5 8192 5 active insts wait > $OUT/pmc.txt 2>&1
-  bash tools/r03_pmc.sh $TAG/pmc_aa1 cluster_s5 8192 1 active insts >> $OUT/pmc.txt 2>&1
+  bash tools/pmc_sets.sh $TAG/pmc_headline cluster_s5 8192 5 active insts wait > $OUT/pmc.txt 2>&1
+  bash tools/pmc_sets.sh $TAG/pmc_aa1 cluster_s5 8192 1 active insts >> $OUT/pmc.txt 2>&1
   tail -c 3000 $OUT/pmc.txt
 fi
