@@ -114,3 +114,22 @@ def test_shards_equal_slices_of_the_full_run_and_runs_are_deterministic():
     for t in range(steps):
       assert np.array_equal(sh_f[t], full_f[t][k * B:(k + 1) * B]), (k, t)
       assert np.array_equal(sh_r[t].view(np.uint64), full_r[t][k * B:(k + 1) * B].view(np.uint64)), (k, t)
+
+
+def test_bench_in_run_verification_on_the_engine():
+  """bench.py's own check of a timed run (gpu_run(verify=...) + verify_against_oracle), on the HIP engine: 0 mismatches over
+  warm-up + timed steps, and a JSON-serialisable block."""
+  import importlib.util
+  import json
+  import os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location('bench', os.path.join(root, 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  for name, aa in (('cluster_s5', 5), ('embodied_s12', 5), ('cluster_s5', 1)):
+    res = bench.gpu_run(name, 512, steps=21, warmup=4, aa=aa, device=0, verify=48)
+    assert res['error'] is None and res['errors'] == 0
+    out = bench.verify_against_oracle(res['sample'])
+    assert out['verified_envs'] == 48 and out['mismatches'] == 0 and out['frame_bytes_differing'] == 0, (name, aa, out)
+    assert out['steps_replayed'] == 25
+    json.dumps(out)
