@@ -151,6 +151,10 @@ typedef struct swb_pool {
   const int32_t* pool_len;    /* [N]                                                  */
   const double* angle;        /* [P,S]   degrees; only for swb_factors (may be NULL)  */
   const double* color;        /* [P,S,3] c0,c1,c2; only for swb_factors (may be NULL) */
+  const uint8_t* attr_f32;    /* [P,S]   bit 0 / bit 1: the sprite's angle / scale is an np.float32 in the reference (what
+                               * factor distributions draw; Discrete candidates and constructor arguments are Python numbers),
+                               * so that a setter takes `a - self._angle` / `s - self._scale` in that type (sprite.py:163,173
+                               * under NEP 50).  May be NULL (= all Python numbers).  swb_sample_pool records it per sprite. */
 } swb_pool;
 
 /* Device-side reset sampling: a declarative form of the sprite
@@ -294,6 +298,8 @@ int swb_factors(swb_handle h, double* factors_dev, void* stream);
  * episode, pool entry it plays, step count, episodes started, 1 if the next step is a reset }.  Synchronises
  * `stream`; five 4-byte copies whatever the batch size (swb_get_state copies every environment). */
 int swb_get_env_state(swb_handle h, int32_t env, int32_t* out5, void* stream);
+/* swb_pool::attr_f32 of one sprite of the episode environment `env` is playing (bit 0: angle, bit 1: scale). */
+int swb_get_sprite_types(swb_handle h, int32_t env, int32_t sprite, int32_t* flags, void* stream);
 
 /* Blocking state access (synchronises `stream`). */
 int swb_get_state(swb_handle h, const swb_state* host_state, void* stream);

@@ -79,6 +79,7 @@ class SwbPool(C.Structure):
       ('pool_len', C.c_void_p),
       ('angle', C.c_void_p),
       ('color', C.c_void_p),
+      ('attr_f32', C.c_void_p),
   ]
 
 

@@ -80,6 +80,7 @@ struct swb_engine {
   int32_t* d_p_shape = nullptr;
   uint32_t* d_p_rgb = nullptr;
   int8_t* d_p_label = nullptr;
+  uint8_t* d_p_attr = nullptr;       // swb_pool::attr_f32
   int32_t *d_pool_base = nullptr, *d_pool_len = nullptr;
   double *d_p_angle = nullptr, *d_p_color = nullptr;
   swb_sampler* d_sampler = nullptr;
@@ -493,7 +494,7 @@ int swb_destroy(swb_handle h) {
     for (auto& ev : *list) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
   void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
-                  h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
+                  h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_p_attr, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
                   h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler,
                   h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label,
                   h->d_cost_cnt, h->d_cost_list, h->d_ccost_list, h->d_runs, h->d_rhdr, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
@@ -646,6 +647,7 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
   rc |= upload(&h->d_p_shape, pool->shape, PS);
   rc |= upload(&h->d_p_rgb, rgb.data(), PS);
   rc |= upload(&h->d_p_label, pool->label, (size_t)P * T * S);
+  rc |= upload(&h->d_p_attr, pool->attr_f32, PS);                      // (NULL: zeros = Python numbers)
   rc |= upload(&h->d_pool_base, pool->pool_base, N);
   rc |= upload(&h->d_pool_len, pool->pool_len, N);
   if (pool->angle) rc |= upload(&h->d_p_angle, pool->angle, PS);
@@ -766,6 +768,7 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
     rc |= upload<double>(&h->d_p_sa, nullptr, PS);
     rc |= upload<int32_t>(&h->d_p_shape, nullptr, PS); rc |= upload<uint32_t>(&h->d_p_rgb, nullptr, PS);
     rc |= upload<int8_t>(&h->d_p_label, nullptr, (size_t)P * T * S);
+    rc |= upload<uint8_t>(&h->d_p_attr, nullptr, PS);
     rc |= upload<double>(&h->d_p_angle, nullptr, PS); rc |= upload<double>(&h->d_p_color, nullptr, PS * 3);
   }
   rc |= upload(&h->d_pool_base, pool_base_host, N);
@@ -779,7 +782,7 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
   p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
   p.p_angle = h->d_p_angle; p.p_color = h->d_p_color;
   swb_sampler_args a{h->d_sampler, P, S, T, seed, first_entry, nullptr, nullptr, nullptr, N, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale,
-                     h->d_p_ca, h->d_p_sa, h->d_p_angle, h->d_p_color, h->d_p_shape, h->d_p_rgb, h->d_p_label};
+                     h->d_p_ca, h->d_p_sa, h->d_p_angle, h->d_p_color, h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_p_attr};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(swb_sample_pool_kernel, dim3((P + 255) / 256), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -803,7 +806,7 @@ int swb_resample_pool(swb_handle h, uint64_t seed, uint64_t first_entry, void* s
   const int P = h->pool_entries, S = h->p.S, T = h->p.n_tasks, N = h->p.N;
   swb_sampler_args a{h->d_sampler, P, S, T, seed, first_entry, h->d_entry, h->d_pool_base, h->d_pool_len, N, h->d_p_n,
                      h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa, h->d_p_angle,
-                     h->d_p_color, h->d_p_shape, h->d_p_rgb, h->d_p_label};
+                     h->d_p_color, h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_p_attr};
   hipLaunchKernelGGL(swb_sample_pool_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return SWB_OK;
@@ -825,6 +828,7 @@ int swb_get_pool(swb_handle h, const swb_pool* pool) {
   SWB_D2H(pool->scale, h->d_p_scale, PS); SWB_D2H(pool->cos_a, h->d_p_ca, PS); SWB_D2H(pool->sin_a, h->d_p_sa, PS);
   SWB_D2H(pool->shape, h->d_p_shape, PS);
   SWB_D2H(pool->label, h->d_p_label, (size_t)P * T * S);
+  SWB_D2H(pool->attr_f32, h->d_p_attr, PS);
   SWB_D2H(pool->pool_base, h->d_pool_base, (size_t)N); SWB_D2H(pool->pool_len, h->d_pool_len, (size_t)N);
   if (h->p.p_angle) SWB_D2H(pool->angle, h->d_p_angle, PS);
   if (h->p.p_color) SWB_D2H(pool->color, h->d_p_color, PS * 3);
@@ -899,6 +903,22 @@ int swb_get_env_state(swb_handle h, int32_t env, int32_t* out5, void* stream) {
   HIP_TRY(hipMemcpy(&out5[3], h->d_episode + env, 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&rn, h->d_reset_next + env, 1, hipMemcpyDeviceToHost));
   out5[4] = rn;
+  return SWB_OK;
+}
+
+int swb_get_sprite_types(swb_handle h, int32_t env, int32_t sprite, int32_t* flags, void* stream) {
+  if (!h || !flags) return fail(SWB_ERR_INVALID, "null argument");
+  if (!h->have_pool) return fail(SWB_ERR_STATE, "no pool on the device");
+  if (env < 0 || env >= h->p.N) return fail(SWB_ERR_INVALID, "environment %d out of range", env);
+  if (sprite < 0 || sprite >= h->p.S) return fail(SWB_ERR_INVALID, "sprite %d out of range", sprite);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  int32_t en = 0;
+  uint8_t f = 0;
+  HIP_TRY(hipMemcpy(&en, h->d_entry + env, 4, hipMemcpyDeviceToHost));
+  if (en < 0 || en >= h->pool_entries) return fail(SWB_ERR_STATE, "environment %d has not been reset yet", env);
+  HIP_TRY(hipMemcpy(&f, h->d_p_attr + (size_t)en * h->p.S + sprite, 1, hipMemcpyDeviceToHost));
+  *flags = f;
   return SWB_OK;
 }
 

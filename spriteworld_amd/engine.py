@@ -162,6 +162,13 @@ class Engine(object):
     _lib.check(self.lib.swb_get_env_state(self._h, int(env), _ptr(out), self._stream()))
     return dict(zip(('n_sprites', 'pool_entry', 'step_count', 'episode', 'reset_next'), (int(v) for v in out)))
 
+  def sprite_types(self, env, sprite):
+    """(angle is np.float32, scale is np.float32) for a sprite of the episode `env` is playing: the types the reference's
+    Sprite holds (swb_pool::attr_f32, recorded by lowering / the device sampler)."""
+    f = C.c_int32(0)
+    _lib.check(self.lib.swb_get_sprite_types(self._h, int(env), int(sprite), C.byref(f), self._stream()))
+    return bool(f.value & 1), bool(f.value & 2)
+
   def set_positions(self, x, y):
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)

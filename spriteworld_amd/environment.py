@@ -315,25 +315,16 @@ class BatchedEnvironment(object):
       self._attr_assigned[(env, sprite, name)] = (episode, getattr(value, 'dtype', None) == np.float32)
 
   def _attr_is_f32(self, env, sprite, name, episode, value):
-    """Is this sprite's angle / scale an np.float32 in the reference?  A value assigned through a setter keeps the
-    type it was given; factor distributions draw float32, Discrete candidates and Sprite() defaults are Python numbers.
-    Host pools record it per sprite; with a device sampler angles are never float32 (Discrete or integer degrees only)
-    and a scale is when every group draws it from a Continuous distribution (generators that mix both: when the current
-    value is float32-representable)."""
+    """Is this sprite's angle / scale an np.float32 in the reference?  A value assigned through a setter keeps the type it
+    was given; otherwise it is what the episode's generator drew -- factor distributions draw float32, Discrete candidates
+    and Sprite() arguments are Python numbers -- which the pool records per sprite (swb_pool::attr_f32: written by
+    `lowering.lower_episodes` from the sprite objects and by the device sampler from the factor's kind)."""
+    del value
     rec = self._attr_assigned.get((env, sprite, name))
     if rec is not None and rec[0] == episode:
       return rec[1]
-    pool = self._engine.pool
-    if pool is not None and getattr(pool, 'attr_f32', None) is not None:
-      return bool(pool.attr_f32[self._engine.env_state(env)['pool_entry'], sprite] & (1 if name == 'angle' else 2))
-    if self._sampler is None or name == 'angle':
-      return False
-    kinds = self._sampler.scale_kinds()
-    if all(k == _abi.FACTOR_UNIFORM_F32 for k in kinds):
-      return True
-    if not any(k == _abi.FACTOR_UNIFORM_F32 for k in kinds):
-      return False
-    return float(np.float32(value)) == float(value)
+    angle_f32, scale_f32 = self._engine.sprite_types(env, sprite)
+    return angle_f32 if name == 'angle' else scale_f32
 
   def close(self):
     self._engine.close()

@@ -221,6 +221,8 @@ class Pool(object):
     self.angle = np.ascontiguousarray(self.angle, dtype=np.float64)
     self.color = np.ascontiguousarray(self.color, dtype=np.float64)
     s.angle, s.color = self.angle.ctypes.data, self.color.ctypes.data
+    self.attr_f32 = np.ascontiguousarray(self.attr_f32, dtype=np.uint8)
+    s.attr_f32 = self.attr_f32.ctypes.data
     return s
 
 

@@ -170,6 +170,12 @@ class EmuEngine(object):
     check(self.lib.swb_get_env_state(self._h, int(env), _ptr(out), None))
     return dict(zip(('n_sprites', 'pool_entry', 'step_count', 'episode', 'reset_next'), (int(v) for v in out)))
 
+  def sprite_types(self, env, sprite):
+    f = C.c_int32(0)
+    self.lib.swb_get_sprite_types.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+    check(self.lib.swb_get_sprite_types(self._h, int(env), int(sprite), C.byref(f), None))
+    return bool(f.value & 1), bool(f.value & 2)
+
   def set_positions(self, x, y):
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)

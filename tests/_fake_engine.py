@@ -62,6 +62,10 @@ class FakeEngine(object):
     st = self._ora.state()
     return {k: int(st[k][env]) for k in ('n_sprites', 'pool_entry', 'step_count', 'episode', 'reset_next')}
 
+  def sprite_types(self, env, sprite):
+    f = int(self.pool.attr_f32[self.env_state(env)['pool_entry'], sprite]) if self.pool is not None else 0
+    return bool(f & 1), bool(f & 2)
+
   def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
     try:
       self._ora.set_sprite_attr(env, sprite, attr, value, delta=delta, label=label)

@@ -523,3 +523,75 @@ def test_model_matches_the_reference_generators_statistically():
   nz = ref_shapes > 0
   assert (got_shapes > 0).tolist() == nz.tolist()
   assert stats.chisquare(got_shapes[nz] * (ref_shapes[nz].sum() / got_shapes[nz].sum()), ref_shapes[nz]).pvalue > 1e-3
+
+
+def _mixed_scale_env(monkeypatch=None, emulated=False):
+  """Two groups whose `scale` factors have different types: Continuous (np.float32 in the reference) and Discrete (Python
+  floats, one of them exactly representable in float32), shuffled so that a slot's group differs from episode to episode."""
+  from spriteworld_amd import environment
+  if emulated:
+    from tests import _emu_engine
+    monkeypatch.setattr(environment._engine, 'Engine', _emu_engine.EmuTorchEngine)
+  common = [distribs.Continuous('x', 0.2, 0.8), distribs.Continuous('y', 0.2, 0.8), distribs.Discrete('shape', ['square', 'triangle']),
+            distribs.Continuous('c0', 0., 1.), distribs.Continuous('c1', 0.5, 1.), distribs.Continuous('c2', 0.9, 1.)]
+  cont = distribs.Product(common + [distribs.Continuous('scale', 0.3, 0.5), distribs.Continuous('angle', 0, 360, dtype='int32')])
+  disc = distribs.Product(common + [distribs.Discrete('scale', [0.1, 0.25]), distribs.Discrete('angle', [0., 45.])])
+  sampler = device_sampler.DeviceSampler([(cont, 2), (disc, 2)], shuffle=True, seed=4)
+  rend = {'image': renderer_lib.PILRenderer(image_size=(32, 32), anti_aliasing=2, color_to_rgb=renderer_lib.hsv_to_rgb)}
+  return environment.BatchedEnvironment(task=tasks.NoReward(), action_space=action_spaces.SelectMove(scale=0.25), renderers=rend,
+                                        init_sprites=sampler, max_episode_length=50, num_envs=24, episodes_per_env=2, refresh_every=0)
+
+
+def _check_recorded_types(env):
+  """swb_pool::attr_f32 as the sampler recorded it: a scale is np.float32 exactly when its group draws it from a Continuous
+  distribution -- read per live sprite (swb_get_sprite_types) and for the whole pool (swb_get_pool) -- and the setters take
+  their difference in that type (round-3 advice: a Discrete 0.25 is float32-representable and was guessed to be float32)."""
+  env.reset()
+  pool = env.engine.get_pool()
+  from_cont = pool.scale >= 0.3
+  assert ((pool.attr_f32 & 2) != 0).tolist() == from_cont.tolist()
+  assert ((pool.attr_f32 & 1) != 0).sum() == 0                     # integer degrees and Discrete angles: never float32
+  seen = set()
+  for e in range(env.num_envs):
+    entry = env.engine.env_state(e)['pool_entry']
+    for k in range(4):
+      angle_f32, scale_f32 = env.engine.sprite_types(e, k)
+      assert scale_f32 == bool(from_cont[entry, k]) and not angle_f32
+      seen.add((scale_f32, float(pool.scale[entry, k]) == 0.25))
+  assert (True, False) in seen and (False, True) in seen
+  # the setter's delta: float32 subtraction for the Continuous sprite, float64 for the Discrete one -- the reference's arithmetic
+  for e in range(6):
+    entry = env.engine.env_state(e)['pool_entry']
+    for k in range(4):
+      old = pool.scale[entry, k]
+      live = env.sprites(e)[k]
+      live.scale = 0.37
+      want = float(np.float32(0.37 - np.float32(old))) if from_cont[entry, k] else 0.37 - float(old)
+      path = live.centered_path
+      base = shapes.SHAPES[live.shape]
+      # sprite.py:171-175: the current path (scale `old`) scaled by the DIFFERENCE; the first vertex tells the factor
+      got = env.engine.get_sprite(e, k)
+      assert got['scale'] == 0.37
+      ref = _scaled_path(base, float(old), float(pool.angle[entry, k]), want)
+      assert np.array_equal(path, ref), (e, k, from_cont[entry, k])
+
+
+def _scaled_path(base, scale, angle, delta):
+  """matplotlib's arithmetic of Sprite._reset_centered_path followed by the scale setter (sprite.py:96-101,171-175)."""
+  from matplotlib import path as mpl_path
+  from matplotlib import transforms as mpl_transforms
+  p = (mpl_transforms.Affine2D().scale(scale) + mpl_transforms.Affine2D().rotate_deg(angle)).transform_path(mpl_path.Path(base))
+  return mpl_transforms.Affine2D().scale(delta).transform_path(p).vertices
+
+
+def test_emulated_sampler_records_the_type_of_every_scale(monkeypatch):
+  env = _mixed_scale_env(monkeypatch, emulated=True)
+  _check_recorded_types(env)
+  env.close()
+
+
+@pytest.mark.gpu
+def test_device_sampler_records_the_type_of_every_scale():
+  env = _mixed_scale_env()
+  _check_recorded_types(env)
+  env.close()
