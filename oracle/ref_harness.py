@@ -22,10 +22,26 @@ STAGED_ROOT = os.path.join(_HERE, '_ref')
 _COMPAT = os.path.join(_HERE, 'compat')
 
 
+def _usable(root):
+  """A reference tree: the package directory exists and, for the staged bytecode, was compiled by this interpreter version
+  (a .pyc of another version cannot be imported: the tree then counts as absent and its users skip)."""
+  if not os.path.isdir(os.path.join(root, 'spriteworld')):
+    return False
+  manifest = os.path.join(root, 'MANIFEST.json')
+  if os.path.exists(manifest):
+    import json
+    try:
+      with open(manifest) as f:
+        return json.load(f).get('python') == '%d.%d' % sys.version_info[:2]
+    except (OSError, ValueError):
+      return False
+  return True
+
+
 def _pick_root():
   env = os.environ.get('SPRITEWORLD_REFERENCE')
   for root in ([env] if env else []) + ['/root/reference', STAGED_ROOT]:
-    if os.path.isdir(os.path.join(root, 'spriteworld')):
+    if _usable(root):
       return root
   return env or '/root/reference'
 
@@ -34,7 +50,7 @@ REFERENCE_ROOT = _pick_root()
 
 
 def reference_available():
-  return os.path.isdir(os.path.join(REFERENCE_ROOT, 'spriteworld'))
+  return _usable(REFERENCE_ROOT)
 
 
 def reference_kind():
