@@ -328,7 +328,7 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   // (and the launch is more than one round of cover waves but not many: one round needs no order, and from about a dozen
   // rounds on the plain order was measured 1.6 % faster)
   {
-    const long long slots = (long long)std::max(h->cus, 1) * 4 * (v->nw <= 10 ? SWB_COVER_WAVES_PER_SIMD : SWB_COVER_WAVES_PER_SIMD_WIDE);
+    const long long slots = (long long)std::max(h->cus, 1) * 4 * SWB_COVER_WAVES(v->nw);
     p.cover_order = (h->cover_lists_filed && p.ccost_list && ((p.N > slots && p.N <= 4 * slots) || h->force_cover_order)) ? 1 : 0;
     if (p.N > 2 * slots) p.prio_levels &= ~2;          // (cover waves' priorities: measured +1.3 % at three rounds of waves)
   }
@@ -1140,7 +1140,7 @@ int swb_variant(swb_handle h, swb_variant_info* out) {
   (void)pick_resample(h->p.AA, h->vslots, &vs);
   out->nw = v->nw; out->ncol = 1; out->vs = vs;
   out->lds_bytes_per_wave = (int32_t)lds_per_wave(h, v, nullptr);
-  out->waves_per_simd = v->nw <= 10 ? SWB_COVER_WAVES_PER_SIMD : SWB_COVER_WAVES_PER_SIMD_WIDE;
+  out->waves_per_simd = SWB_COVER_WAVES(v->nw);
   out->resample_waves_per_simd = SWB_RS_WAVES_PER_SIMD;
   out->n_bands = h->p.nbands ? h->p.nbands : h->nbands;
   out->n_column_groups = (h->p.Wo + 63) / 64;
