@@ -59,6 +59,16 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     labels = [[0]] * 2 + [[1]] * 3
     pool = synthetic.make_pool(rng, P, 5, hues, labels)
     cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 5, True)
+  elif name == 'cluster_s5_st':
+    # the headline scene with squares and triangles only (episodes of at most 20 polygon vertices: a small LDS footprint --
+    # used to measure the cover kernel at occupancies its usual footprint does not allow)
+    task = tasks.Clustering([None, None], terminate_bonus=0., reward_range=10.)
+    aspace = action_spaces.SelectMove(scale=0.25)
+    rend = _renderers(64, aa)
+    hues = [(0.55, 0.65)] * 2 + [(0.27, 0.37)] * 3
+    labels = [[0]] * 2 + [[1]] * 3
+    pool = synthetic.make_pool(rng, P, 5, hues, labels, shape_names=('square', 'triangle'))
+    cfg = lowering.lower_config(task, aspace, rend, True, 50, num_envs, 5, True)
   elif name == 'cluster6_s12':
     # six clusters of two (a 6 x 6 Davies-Bouldin ratio matrix), float32 positions; one sprite in no cluster
     task = tasks.Clustering([None] * 6, termination_threshold=1.2, terminate_bonus=1., reward_range=6.)
