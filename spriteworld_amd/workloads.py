@@ -78,6 +78,16 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
     labels = [[i] for i in range(6) for _ in range(2)] + [[-1]]
     pool = synthetic.make_pool(rng, P, 13, hues, labels, scales=(0.06, 0.09))
     cfg = lowering.lower_config(task, aspace, rend, True, 30, num_envs, 13, True)
+  elif name == 'cluster9_s16':
+    # nine clusters (seven pairs, two singletons) of 16 sprites: a 9 x 9 Davies-Bouldin ratio matrix -- more rows than the
+    # kernel's 64 lanes take in one pass (7 rows of 9) -- in float32 positions
+    task = tasks.Clustering([None] * 9, termination_threshold=1.2, terminate_bonus=1., reward_range=6.)
+    aspace = action_spaces.SelectMove(scale=0.25)
+    rend = _renderers(64, aa)
+    hues = [(0.08 * i, 0.08 * i + 0.05) for i in range(7) for _ in range(2)] + [(0.6, 0.65), (0.7, 0.75)]
+    labels = [[i] for i in range(7) for _ in range(2)] + [[7], [8]]
+    pool = synthetic.make_pool(rng, P, 16, hues, labels, scales=(0.06, 0.09))
+    cfg = lowering.lower_config(task, aspace, rend, True, 30, num_envs, 16, True)
   elif name.startswith('geom_'):
     # image geometry sweep: geom_<W>x<H> (non-square, wide images; anti_aliasing from the argument)
     w, h = (int(v) for v in name[len('geom_'):].split('x'))

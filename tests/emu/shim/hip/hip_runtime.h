@@ -166,6 +166,7 @@ template <typename T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; retur
 template <typename T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
+template <typename T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 #define __hip_atomic_load(p, order, scope) (*(p))

@@ -63,7 +63,7 @@ def _run(name, n_envs, steps, aa, seed=0):
 # the workloads of tests/test_gpu_parity.py (every kernel variant, every task / action space / dtype), a few environments each
 @pytest.mark.parametrize('name,n_envs,steps,aa', [
     ('goal_s5', 3, 4, 5), ('cluster_s5', 3, 4, 5), ('goal_s5', 3, 3, 1), ('cluster_s5', 3, 3, 1), ('embodied_s12', 2, 3, 5),
-    ('sorting_s4', 3, 4, 5), ('f64_drag', 4, 5, 3), ('f64_cluster', 4, 5, 3), ('cluster6_s12', 3, 4, 2), ('ragged_s16', 8, 4, 5),
+    ('sorting_s4', 3, 4, 5), ('f64_drag', 4, 5, 3), ('f64_cluster', 4, 5, 3), ('cluster6_s12', 3, 4, 2), ('cluster9_s16', 3, 4, 2), ('ragged_s16', 8, 4, 5),
     ('ragged_s16_embodied', 8, 4, 5), ('wide_s4', 2, 3, 5), ('wide_s4', 2, 3, 1), ('tiny_s6', 4, 3, 5), ('tiny_s6', 4, 3, 1),
     ('goal_s5_f32a', 3, 4, 5), ('cluster_s5_f32a', 3, 4, 5), ('f64_drag_f32a', 3, 4, 3), ('f64_cluster_f32a', 3, 4, 3),
     ('sorting_s4_f32a', 3, 4, 5)])

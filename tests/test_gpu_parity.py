@@ -84,6 +84,10 @@ def test_six_clusters_scalar_davies_bouldin_path():
   _run('cluster6_s12', 128, 25, 2)
 
 
+def test_nine_clusters_ratio_matrix_in_two_passes():
+  _run('cluster9_s16', 128, 25, 2)
+
+
 @pytest.mark.parametrize('name', ['ragged_s16', 'ragged_s16_embodied'])
 def test_ragged_sprite_counts_zero_to_sixteen(name):
   _run(name, 128, 20, 5)
