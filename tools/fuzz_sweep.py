@@ -23,6 +23,9 @@ def main():
       bad.append(seed)
       out.write('seed %d FAILED\n%s\n' % (seed, traceback.format_exc()[-1500:]))
       out.flush()
+    if (seed + 1 - first) % 50 == 0:          # (progress: a sweep cut by a timeout still says how far it got)
+      out.write('... seeds [%d, %d): %d failed so far\n' % (first, seed + 1, len(bad)))
+      out.flush()
   out.write('fuzz seeds [%d, %d): %d passed, %d failed %s\n' % (first, last, last - first - len(bad), len(bad), bad))
   out.flush()
 
