@@ -298,6 +298,7 @@ class BatchedEnvironment(object):
     attr = {'shape': _abi.ATTR_SHAPE, 'angle': _abi.ATTR_ANGLE, 'scale': _abi.ATTR_SCALE}[name]
     live = sprite_lib.LiveSprite(self, env, sprite)
     factors = live.factors
+    before = factors[name]               # (one read of the sprite serves the labels and the setter's difference)
     factors[name] = value
     proxy = collections.namedtuple('_Factors', ['factors'])(factors)
     label = np.array([lowering._label_of(sub, proxy) for sub in lowering.subtasks_of(self._task)], dtype=np.int8)  # pylint: disable=protected-access
@@ -306,7 +307,7 @@ class BatchedEnvironment(object):
     if name != 'shape':
       # sprite.py:163,173 take `a - self._angle` / `s - self._scale` with whatever types the two carry: an np.float32
       # attribute (factor distributions draw float32) makes it a float32 subtraction under NEP 50.  numpy decides here too.
-      old = getattr(live, name)
+      old = before
       old = np.float32(old) if self._attr_is_f32(env, sprite, name, episode, old) else float(old)
       delta = float(value - old)
     self._engine.set_sprite_attr(env, sprite, attr, shapes_lib.shape_index(value) if name == 'shape' else float(value),

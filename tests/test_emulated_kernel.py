@@ -72,7 +72,7 @@ def test_emulated_kernel_equals_oracle(name, n_envs, steps, aa):
 
 
 @pytest.mark.parametrize('geom,aa', [('96x48', 3), ('48x96', 2), ('256x64', 2), ('160x160', 4), ('128x128', 1),
-                                     ('100x60', 3), ('64x256', 1), ('32x32', 8)])
+                                     ('100x60', 3), ('64x256', 1), ('32x32', 8), ('32x512', 4)])
 def test_emulated_kernel_image_geometries(geom, aa):
   _run('geom_' + geom, 2, 2, aa)
 
