@@ -64,13 +64,22 @@ def main():
   c = t[0, :n_envs]
   names = ['loads+paths', 'hit/move', 'task', 'edges(P1b)']
   prev = np.zeros(n_envs)
+  if os.environ.get('EXP_P2'):      # the library of tools/overlays/trace_p2.py: cycle sums inside P2 instead of the phase stamps
+    for i, nm in enumerate(['head', 'scatter', 'fence', 'words']):
+      res['cover_p2_cycles_' + nm] = pct(c[:, 4 + i])
+    res['cover_p2_cycles_tail'] = pct(c[:, 11])
+    for k in sorted(res):
+      if k.startswith('cover_p2'):
+        print(k, res[k])
+    names = []
   for i, nm in enumerate(names):
     res['cover_phase_cycles_' + nm] = pct(c[:, 4 + i] - prev)
     prev = c[:, 4 + i]
   res['cover_phase_cycles_coverage'] = pct(c[:, 8])
   res['cover_phase_cycles_emit'] = pct(c[:, 9])
   res['cover_batches'] = pct(c[:, 10])
-  res['cover_phase_cycles_rest'] = pct(c[:, 2] - prev - c[:, 8] - c[:, 9])
+  if names:
+    res['cover_phase_cycles_rest'] = pct(c[:, 2] - prev - c[:, 8] - c[:, 9])
   for k in sorted(res):
     if k.startswith('cover_phase') or k == 'cover_batches':
       print(k, res[k])
