@@ -1,7 +1,11 @@
 """P2: the edge records of the NEXT sprite of a batch fetched while the current sprite's pass runs (experiment; results
 unchanged).  In the edge-lane form every lane reads its edge's 16-byte record from LDS at the head of a pass and waits for
 it (~130-200 cycles of a pass of ~4 100, wave timelines of round 4); here lane l issues the read for the next pass -- sprite
-parameters of the next sprite through the two v_readlane the pass would do anyway -- right after taking over its own."""
+parameters of the next sprite through the two v_readlane the pass would do anyway -- right after taking over its own.
+
+Measured (round 4, profiles/r04_experiments/queued_overlays_ab.txt): on top of scatter_unswitch it takes the whole gain back
+(cover 0.0836 -> 0.0862 ms at 8192 envs, 0.0392 -> 0.0398 at 1024): the record held across the pass and the second set of
+sprite parameters cost more (98 instead of 89 spilled SGPRs) than the LDS round trip they hide.  Kept as a record."""
 
 
 def apply(files, arg, replace_once):
