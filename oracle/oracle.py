@@ -48,11 +48,16 @@ def lib():
     _lib.swo_contains_point.argtypes = [C.c_int] + [C.c_double] * 5
     _lib.swo_set_sprite_attr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
     _lib.swo_get_sprite.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
-    verts, offs = _shapes.packed_table()
-    rc = _lib.swo_set_shapes(verts.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
-                             C.c_int32(len(offs) - 1))
-    assert rc == 0
+    set_shapes()
   return _lib
+
+
+def set_shapes():
+  """(Re)loads the shape table of spriteworld_amd.shapes into the oracle (tests swap a shape for one of 33 .. 64 vertices, which
+  the C ABI allows and no built-in shape exercises)."""
+  verts, offs = _shapes.packed_table()
+  rc = _lib.swo_set_shapes(verts.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), C.c_int32(len(offs) - 1))
+  assert rc == 0
 
 
 def _p(a):

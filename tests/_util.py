@@ -1,4 +1,5 @@
 """Shared helpers for the tests."""
+import contextlib
 import ctypes
 import glob
 import os
@@ -11,6 +12,22 @@ from spriteworld_amd import lowering
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@contextlib.contextmanager
+def swapped_shape(name, verts):
+  """`name` of the shape table replaced by `verts` for the engines created inside the block (the oracle's table follows)."""
+  from oracle import oracle
+  from spriteworld_amd import shapes
+  oracle.lib()
+  old = shapes.SHAPES[name]
+  shapes.SHAPES[name] = np.asarray(verts, dtype=np.float64)
+  oracle.set_shapes()
+  try:
+    yield
+  finally:
+    shapes.SHAPES[name] = old
+    oracle.set_shapes()
 
 
 def golden_cases():

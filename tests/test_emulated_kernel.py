@@ -71,6 +71,17 @@ def test_emulated_kernel_equals_oracle(name, n_envs, steps, aa):
   _run(name, n_envs, steps, aa)
 
 
+@pytest.mark.parametrize('n_vertices', [33, 40, 64])
+@pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 3, 5), ('goal_s5', 3, 1), ('tiny_s6', 4, 5)])
+def test_emulated_kernel_shapes_of_33_to_64_edges(n_vertices, name, n_envs, aa):
+  """The C ABI takes shapes of up to SWB_MAX_SHAPE_VERTS = 64 vertices; from 33 on an edge gets ONE lane of the edge-lane scatter
+  (G = 64 / n_edges = 1), whose lane -> edge reciprocal is then 2^16 itself (round 4 packed it in 16 bits: every lane served
+  edge 0 -- ADVICE round 4).  No built-in shape has more than 30 vertices: the circle is swapped for a regular n-gon."""
+  from spriteworld_amd import shapes
+  with _util.swapped_shape('circle', shapes.polygon(n_vertices)):
+    _run(name, n_envs, 3, aa)
+
+
 @pytest.mark.parametrize('geom,aa', [('96x48', 3), ('48x96', 2), ('256x64', 2), ('160x160', 4), ('128x128', 1),
                                      ('100x60', 3), ('64x256', 1), ('32x32', 8), ('32x512', 4)])
 def test_emulated_kernel_image_geometries(geom, aa):

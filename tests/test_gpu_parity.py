@@ -105,6 +105,17 @@ def test_wide_sprites_aa1():
   _run('wide_s4', 128, 8, 1)
 
 
+@pytest.mark.parametrize('n_vertices', [33, 40, 64])
+@pytest.mark.parametrize('name,aa', [('cluster_s5', 5), ('goal_s5', 1), ('tiny_s6', 5)])
+def test_shapes_of_33_to_64_edges(n_vertices, name, aa):
+  """Shapes beyond 32 edges (the C ABI allows 64): one lane per edge in the edge-lane scatter -- ADVICE round 4 (every lane served
+  edge 0).  The circle of the shape table is swapped for a regular n-gon on both sides."""
+  from spriteworld_amd import shapes
+  from tests import _util
+  with _util.swapped_shape('circle', shapes.polygon(n_vertices)):
+    _run(name, 128, 8, aa)
+
+
 def test_tiny_sprites_degenerate_polygons():
   _run('tiny_s6', 256, 10, 5)
 

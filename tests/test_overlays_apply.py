@@ -8,9 +8,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OVERLAYS = [['phase_cut:3'], ['phase_cut:4'], ['phase_cut:5'], ['phase_cut:1'], ['trace'], ['trace_p2'], ['scatter_unswitch'],
-            ['rowlane_unswitch'], ['edge_prefetch'], ['scatter2x'], ['covered_init_clip'], ['edge_prefetch', 'scatter_unswitch', 'rowlane_unswitch'],
-            ['scatter_unswitch', 'covered_init_clip']]
+OVERLAYS = [['phase_cut:3'], ['phase_cut:4'], ['phase_cut:5'], ['phase_cut:1'], ['trace'], ['trace_p2'],
+            ['rowlane_unswitch']]
 
 
 def _overlay_build():
