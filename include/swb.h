@@ -289,6 +289,11 @@ int swb_step(swb_handle h, const void* actions_dev, const swb_outputs* out, void
 /* observation() only (no state change): obs_dev u8[N,H,W,3]. */
 int swb_render(swb_handle h, uint8_t* obs_dev, void* stream);
 
+/* Environment.success() (/root/reference/spriteworld/environment.py:80-81: `task.success(self._sprites)` of the sprites AS
+ * THEY ARE -- after sprite setters or swb_set_positions, not as the last step left them): success_dev u8[N].  Evaluates the
+ * task (tasks.py:153-158, :239-245, :289-296) in the cover kernel's state phase; no state change, no time step, no frame. */
+int swb_evaluate(swb_handle h, uint8_t* success_dev, void* stream);
+
 /* SpriteFactors observation (renderers/handcrafted.py:29-82): factors_dev f64[N,S,10] in
  * sprite.FACTOR_NAMES order (x, y, shape, angle, scale, c0, c1, c2, x_vel, y_vel), `shape` as its
  * constants.ShapeType value (1-based); rows >= n_sprites[env] are zero. */

@@ -43,6 +43,7 @@ def lib():
     _lib.swo_reset_all.argtypes = [C.c_void_p]
     _lib.swo_step_range.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
     _lib.swo_render_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    _lib.swo_evaluate_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     _lib.swo_get_state.argtypes = [C.c_void_p, C.c_void_p]
     _lib.swo_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _lib.swo_contains_point.argtypes = [C.c_int] + [C.c_double] * 5
@@ -181,6 +182,12 @@ class Engine(object):
     obs = np.zeros((self.N,) + self.obs_shape, dtype=np.uint8)
     lib().swo_render_range(self._h, 0, self.N, _p(obs))
     return obs
+
+  def evaluate(self):
+    """environment.py:80-81: task.success() of the current sprites."""
+    ok = np.zeros(self.N, dtype=np.uint8)
+    lib().swo_evaluate_range(self._h, 0, self.N, _p(ok))
+    return ok
 
   def state(self):
     st = {

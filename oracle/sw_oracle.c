@@ -956,6 +956,12 @@ int swo_render_range(swo_engine* e, int i0, int i1, uint8_t* obs) {
   return 0;
 }
 
+/* environment.py:80-81 Environment.success(): task.success() of the sprites as they are, no time step. */
+int swo_evaluate_range(swo_engine* e, int i0, int i1, uint8_t* success) {
+  for (int i = i0; i < i1; ++i) observe(e, i, NULL, success + i, NULL, NULL);
+  return 0;
+}
+
 int swo_get_state(swo_engine* e, const swb_state* st) {
   const int N = e->cfg.n_envs, S = e->cfg.max_sprites;
   if (st->x) memcpy(st->x, e->x, sizeof(double) * N * S);

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('SWB_LIBRARY') or os.path.join(_HERE, 'csrc', 'libswb.
 # Every symbol include/swb.h declares (tests check the library exports them all).
 EXPORTS = (
     'swb_last_error', 'swb_version', 'swb_create', 'swb_destroy', 'swb_upload_shapes',
-    'swb_upload_resample', 'swb_set_pool', 'swb_sample_pool', 'swb_resample_pool', 'swb_get_pool', 'swb_reset_all', 'swb_step', 'swb_render', 'swb_factors',
+    'swb_upload_resample', 'swb_set_pool', 'swb_sample_pool', 'swb_resample_pool', 'swb_get_pool', 'swb_reset_all', 'swb_step', 'swb_render', 'swb_evaluate', 'swb_factors',
     'swb_get_state', 'swb_set_positions', 'swb_variant', 'swb_build_id', 'swb_timing_enable', 'swb_step_time_ms',
     'swb_set_sprite_attr', 'swb_get_sprite', 'swb_sprite_path_op', 'swb_kernel_times_ms', 'swb_get_env_state',
     'swb_get_sprite_types',
@@ -57,6 +57,7 @@ def load():
   lib.swb_reset_all.argtypes = [C.c_void_p, C.c_void_p]
   lib.swb_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.SwbOutputs), C.c_void_p]
   lib.swb_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+  lib.swb_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   lib.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   lib.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
   lib.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

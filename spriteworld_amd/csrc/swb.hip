@@ -163,12 +163,18 @@ size_t lds_per_wave(const swb_engine* h, const variant* v, int* cpath_in_masks) 
 
 // Overflow slots for the span lists of the cover kernel: one per wave that can be resident at once (occupancy of
 // the kernel that will be launched with its LDS footprint x CUs, capped by the batch), never one per environment.
-int ensure_overflow_slots(swb_engine* h, kernel_fn fn, size_t lds_bytes) {
+// (fn_alt: the other build of the same family -- the one that paints the frame itself / the one that does not --, which a
+// launch with / without an observation buffer switches to: the slots are sized once for the more demanding of the two)
+int ensure_overflow_slots(swb_engine* h, kernel_fn fn, kernel_fn fn_alt, size_t lds_bytes) {
   if (h->d_ovf) return 0;
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), SWB_WAVE, lds_bytes) != hipSuccess ||
-      per_cu < 1)
-    per_cu = 32;
+  for (kernel_fn f : {fn, fn_alt}) {
+    int n = 0;
+    if (!f) continue;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(f), SWB_WAVE, lds_bytes) != hipSuccess || n < 1)
+      n = 32;
+    per_cu = std::max(per_cu, n);
+  }
   HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
   long long slots = (long long)per_cu * cus;
   slots = std::min<long long>(2 * slots, (long long)h->p.N);              // the bitmap stays at most half full: few retries
@@ -297,16 +303,19 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   const kernel_fn fn = paint ? (h->d_ov_flag ? v->fn_paint_ov : v->fn_paint) : (h->d_ov_flag ? v->fn_ov : v->fn);
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // first launch, a new pool that shrank the LDS footprint (more waves resident), or the switch to the override build
-  if (!h->d_ovf || (int)lds < h->ovf_lds_bytes || fn != h->ovf_fn) {
+  // first launch, a new pool that shrank the LDS footprint (more waves resident), or the switch to the override build -- not
+  // the switch between the painting and the plain build of a family, which alternating launches with and without an
+  // observation buffer make at every launch (the cache is keyed on the family's plain build)
+  const kernel_fn fn_family = h->d_ov_flag ? v->fn_ov : v->fn;
+  if (!h->d_ovf || (int)lds < h->ovf_lds_bytes || fn_family != h->ovf_fn) {
     if (h->d_ovf) {
       HIP_TRY(hipDeviceSynchronize());
       (void)hipFree(h->d_ovf); (void)hipFree(h->d_ovf_bitmap);
       h->d_ovf = nullptr; h->d_ovf_bitmap = nullptr;
     }
-    if (int rc = ensure_overflow_slots(h, fn, lds)) return rc;
+    if (int rc = ensure_overflow_slots(h, fn_family, h->d_ov_flag ? v->fn_paint_ov : v->fn_paint, lds)) return rc;
     h->ovf_lds_bytes = (int)lds;
-    h->ovf_fn = fn;
+    h->ovf_fn = fn_family;
     p.ovf = h->p.ovf; p.ovf_bitmap = h->p.ovf_bitmap; p.ovf_slots = h->p.ovf_slots;
   }
   swb_engine::step_events ev = {nullptr, nullptr, nullptr};
@@ -864,6 +873,15 @@ int swb_render(swb_handle h, uint8_t* obs_dev, void* stream) {
   memset(&out, 0, sizeof(out));
   out.obs = obs_dev;
   return launch(h, nullptr, &out, 1, (hipStream_t)stream);
+}
+
+int swb_evaluate(swb_handle h, uint8_t* success_dev, void* stream) {
+  if (!h || !success_dev) return fail(SWB_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  swb_outputs out;
+  memset(&out, 0, sizeof(out));
+  out.success = success_dev;
+  return launch(h, nullptr, &out, 2, (hipStream_t)stream);
 }
 
 int swb_factors(swb_handle h, double* factors_dev, void* stream) {

@@ -136,6 +136,12 @@ class Engine(object):
     _lib.check(self.lib.swb_render(self._h, C.c_void_p(self.obs.data_ptr()), self._stream()))
     return self.obs
 
+  def evaluate(self):
+    """task.success() of the sprites as they are now (environment.py:80-81), into `self.success`: after sprite setters or
+    set_positions the flag of the last step no longer describes them."""
+    _lib.check(self.lib.swb_evaluate(self._h, C.c_void_p(self.success.data_ptr()), self._stream()))
+    return self.success
+
   def factors(self):
     """SpriteFactors observation: f64 [N, S, 10] device tensor (FACTOR_NAMES order, shape as ShapeType id)."""
     if getattr(self, '_factors', None) is None:

@@ -376,7 +376,13 @@ class Environment(object):
 
   `device_reset` defaults to False here -- unlike BatchedEnvironment's 'auto' -- on purpose: the N = 1 form exists to be
   swapped for the reference class (example_run_loop.py:62-80), and calling `init_sprites()` on the host at every reset keeps
-  the episodes those of the reference under the same np.random.seed()."""
+  the episodes those of the reference under the same np.random.seed().
+
+  The episode sequence is the reference's: the k-th call of `init_sprites()` plays the same part in both.  Call 0 -- pool
+  entry 0 -- is the sprites the reference's CONSTRUCTOR draws (`self._sprites = self._init_sprites()`, environment.py:68):
+  what `state()`, `observation()`, `success()` ... see before the first step, never an episode that is stepped; the first
+  `reset()` / `step()` plays call 1, the next one call 2, ...  Whether the caller looks at the state first changes nothing
+  (the pool, `episodes_per_pool` calls, is drawn up front and again when it is used up)."""
 
   def __init__(self, task, action_space, renderers, init_sprites, keep_in_frame=True,
                max_episode_length=1000, metadata=None, episodes_per_pool=32, device=0,
@@ -389,6 +395,7 @@ class Environment(object):
     self._episodes_per_pool = episodes_per_pool
     self._episodes_used = 0
     self._reset_next_step = True
+    self._started = False           # the constructor's sprites (pool entry 0) are on the device
 
   @property
   def action_space(self):
@@ -426,6 +433,7 @@ class Environment(object):
     self._episodes_used += 1
 
   def reset(self):
+    self._ensure_started()
     self._maybe_refill()
     ts = self._convert(self._batched.reset())
     self._reset_next_step = False
@@ -443,17 +451,20 @@ class Environment(object):
   # ---- the rest of the reference's public surface (environment.py:80-86,110-142), acting on the device state
   def _ensure_started(self):
     """The reference's constructor already holds sprites (`self._sprites = self._init_sprites()`, environment.py:68), so
-    its introspection methods work before the first step; here the first episode is put on the device instead.  The first
-    `step()` still resets (environment.py:90-91) and draws the next episode, as the reference does."""
-    if self._episodes_used == 0:
+    its introspection methods work before the first step: pool entry 0 is put on the device for them, once, by the first
+    call of anything -- `reset()` included, so the episodes that are stepped start with entry 1 whether or not anybody
+    looked at the constructor's sprites.  The first `step()` still resets (environment.py:90-91), as the reference does."""
+    if not self._started:
+      self._started = True
       self._maybe_refill()
       self._batched.reset()
 
   def success(self):
-    """environment.py:80-81: `task.success(sprites)` of the current sprites -- the flag the cover kernel evaluated when it
-    last changed them (task evaluation is part of every step and reset)."""
+    """environment.py:80-81: `task.success(sprites)` of the sprites as they are NOW -- evaluated on the device (swb_evaluate:
+    the cover kernel's task phase, no time step), so that a setter or `set_positions` since the last step is seen, as the
+    reference sees it."""
     self._ensure_started()
-    return bool(self._batched.engine.success[0].item())
+    return bool(self._batched.engine.evaluate()[0].item())
 
   def should_terminate(self):
     """environment.py:83-86."""

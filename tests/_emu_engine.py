@@ -39,6 +39,7 @@ def lib():
     l.swb_reset_all.argtypes = [C.c_void_p, C.c_void_p]
     l.swb_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.SwbOutputs), C.c_void_p]
     l.swb_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    l.swb_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     l.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     l.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
     l.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -147,6 +148,10 @@ class EmuEngine(object):
     check(self.lib.swb_render(self._h, _ptr(self.obs), None))
     return self.obs
 
+  def evaluate(self):
+    check(self.lib.swb_evaluate(self._h, _ptr(self.success), None))
+    return self.success
+
   def factors(self):
     out = np.zeros((self.N, self.S, 10), dtype=np.float64)
     check(self.lib.swb_factors(self._h, _ptr(out), None))
@@ -237,6 +242,10 @@ class EmuTorchEngine(EmuEngine):
   def render(self):
     check(self.lib.swb_render(self._h, _ptr(self._np['obs']), None))
     return self.obs
+
+  def evaluate(self):
+    check(self.lib.swb_evaluate(self._h, _ptr(self._np['success']), None))
+    return self.success
 
   def factors(self):
     import torch

@@ -52,6 +52,10 @@ class FakeEngine(object):
     self.obs.copy_(torch.from_numpy(self._ora.render()))
     return self.obs
 
+  def evaluate(self):
+    self.success.copy_(torch.from_numpy(self._ora.evaluate()))
+    return self.success
+
   def outputs_host(self):
     return {k: getattr(self, k).numpy().copy() for k in ('obs', 'reward', 'discount', 'step_type', 'success', 'error')}
 
@@ -65,6 +69,9 @@ class FakeEngine(object):
   def sprite_types(self, env, sprite):
     f = int(self.pool.attr_f32[self.env_state(env)['pool_entry'], sprite]) if self.pool is not None else 0
     return bool(f & 1), bool(f & 2)
+
+  def set_positions(self, x, y):
+    self._ora.set_positions(x, y)
 
   def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
     try:

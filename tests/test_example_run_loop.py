@@ -52,10 +52,9 @@ def _run_main(monkeypatch, run_loop, episodes, use_dropin, steps):
   def get_config(mode):
     nonlocal it
     config = real.get_config(mode)
-    if use_dropin:        # the drop-in draws its pool up front: episode k is the k-th call
-      it = (copy.deepcopy(e) for e in episodes)
-    else:                 # the reference's constructor calls init_sprites() once itself (environment.py:68)
-      it = (copy.deepcopy(e) for e in [episodes[0]] + episodes)
+    # the same calls for both: call 0 is the constructor's (environment.py:68; the drop-in: pool entry 0, never stepped),
+    # call k >= 1 the k-th episode (the drop-in draws them up front, as one pool)
+    it = (copy.deepcopy(e) for e in [episodes[0]] + episodes)
     config['init_sprites'] = lambda: next(it)
     config['max_episode_length'] = 25
     return config
@@ -74,7 +73,7 @@ def _run_main(monkeypatch, run_loop, episodes, use_dropin, steps):
 
     def __init__(self, **kwargs):
       if use_dropin:
-        kwargs['episodes_per_pool'] = len(episodes)
+        kwargs['episodes_per_pool'] = len(episodes) + 1
       base.__init__(self, **kwargs)
 
     def step(self, action):

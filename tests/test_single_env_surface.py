@@ -44,8 +44,8 @@ def _pair(episodes, metadata=None, max_episode_length=9, embodied=False):
       for e in episodes:
         yield copy.deepcopy(e)
 
-  it_ref = cycle([episodes[0]])       # the reference constructor draws once itself (environment.py:68)
-  it_our = cycle([])                  # the drop-in draws its pool of len(episodes) up front, and again when it is used up
+  it_ref = cycle([episodes[0]])       # the same calls for both: the first one is the constructor's (environment.py:68),
+  it_our = cycle([episodes[0]])       # which the drop-in keeps as pool entry 0 and never steps
   ref = environment.Environment(task, aspace, rends, lambda: next(it_ref), keep_in_frame=False,
                                 max_episode_length=max_episode_length, metadata=metadata)
   ours = amd_environment.Environment(task, aspace, rends, lambda: next(it_our), keep_in_frame=False,
@@ -82,6 +82,51 @@ def test_observation_success_and_should_terminate_follow_the_reference(monkeypat
     assert bool(ref.should_terminate()) == ours.should_terminate(), t   # :83-86 (timeout, out of frame -- velocities carry sprites out --, success)
     terminated += bool(ref.should_terminate())
   assert terminated >= 4
+  ours.close()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_success_sees_what_changed_since_the_last_step(monkeypatch, backend):
+  """environment.py:80-81 evaluates the task on the sprites as they ARE: positions written or a setter called since the last
+  step count (the drop-in returned the last launch's flag)."""
+  ref_harness.load_reference()
+  _use_backend(monkeypatch, backend)
+  from spriteworld import action_spaces, environment, renderers, tasks
+  from spriteworld import factor_distributions as distribs
+  from spriteworld_amd import environment as amd_environment
+  # (a) positions: every sprite put on the goal
+  ref, ours = _pair(_episodes(7), max_episode_length=50)
+  a = np.array([0., 0., 0.5, 0.5])
+  for _ in range(3):
+    ref.step(a), ours.step(a)
+  assert not ref.success() and not ours.success()
+  for s in ref._sprites:
+    s._position = np.array([0.5, 0.5])
+  st = ours.soa_state()
+  ours._batched.engine.set_positions(np.full_like(st['x'], 0.5), np.full_like(st['y'], 0.5))
+  assert ref.success() and ours.success()
+  assert ref.should_terminate() and ours.should_terminate()
+  assert ref.state()['global_state']['success'] and ours.state()['global_state']['success']
+  ours.close()
+  # (b) a setter under a filter keyed on the attribute it sets: a sprite far from the goal leaves the task's filter
+  eps = _episodes(9)
+  for e in eps:
+    for i, s in enumerate(e):
+      s._scale = 0.1
+      s._position = np.array([0.5, 0.5]) if i else np.array([0.9, 0.1])
+      s._velocity = np.zeros(2)
+  task = tasks.FindGoalPosition(filter_distrib=distribs.Continuous('scale', 0.05, 0.2), goal_position=(0.5, 0.5), terminate_distance=0.1)
+  rends = {'image': renderers.PILRenderer(image_size=(64, 64), anti_aliasing=5, color_to_rgb=renderers.color_maps.hsv_to_rgb),
+           'success': renderers.Success()}
+  mk = lambda mod, **kw: mod.Environment(task, action_spaces.SelectMove(scale=0.), rends, (lambda it=iter([copy.deepcopy(e) for e in [eps[0]] + eps]): next(it)),
+                                         keep_in_frame=False, max_episode_length=50, **kw)
+  ref, ours = mk(environment), mk(amd_environment, episodes_per_pool=len(eps) + 1)
+  for _ in range(2):
+    ref.step(a), ours.step(a)
+  assert not ref.success() and not ours.success()
+  ref.state()['sprites'][0].scale = 0.4          # sprite.py:166-175; out of the filter: the others are on the goal
+  ours.state()['sprites'][0].scale = 0.4
+  assert ref.success() and ours.success()
   ours.close()
 
 
@@ -123,6 +168,14 @@ def test_state_is_the_references_dict(monkeypatch, backend):
   assert [s.shape for s in s0['sprites']] == [s.shape for s in r0['sprites']]
   assert np.array_equal(early.observation()['image'], ref0.observation()['image'])
   assert early.step(np.zeros(4)).first()
+  # ... and having looked changes nothing: the episodes that are stepped are the reference's (looking
+  # used to consume an episode, so that every later episode was the next draw)
+  assert ref0.step(np.zeros(4)).first()
+  rng0 = np.random.RandomState(6)
+  for t in range(20):                 # max_episode_length = 6: four episodes
+    a = rng0.uniform(0, 1, 4)
+    tr, to = ref0.step(a), early.step(a)
+    assert int(tr.step_type) == int(to.step_type) and np.array_equal(tr.observation['image'], to.observation['image']), t
   early.close()
   ref, ours = _pair(_episodes(5), metadata=meta, max_episode_length=6)
   rng = np.random.RandomState(4)
