@@ -57,7 +57,8 @@ def load():
   lib.swb_reset_all.argtypes = [C.c_void_p, C.c_void_p]
   lib.swb_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.SwbOutputs), C.c_void_p]
   lib.swb_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-  lib.swb_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+  if hasattr(lib, 'swb_evaluate') or not os.environ.get('SWB_LIBRARY'):     # (A/B builds of older revisions lack it)
+    lib.swb_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   lib.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   lib.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
   lib.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OVERLAYS = [['phase_cut:3'], ['phase_cut:4'], ['phase_cut:5'], ['phase_cut:1'], ['trace'], ['trace_p2'],
-            ['rowlane_unswitch']]
+            ['rowlane_unswitch'], ['nofile']]
 
 
 def _overlay_build():

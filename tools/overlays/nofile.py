@@ -1,0 +1,14 @@
+"""Upper bound of what the filing atomics cost on the cover wave's critical path (experiment; frames unchanged, dispatch order
+degraded): every (environment, column group) is filed in bucket 0 of its shard at a position derived from its index -- no
+returning atomic at the end of the wave.  Run with SWB_NO_COVER_ORDER=1 (no second filing) on both sides of the comparison."""
+
+
+def apply(files, arg, replace_once):
+  k = 'swb_kernels.hip.inc'
+  replace_once(files, k, '    const int key0 = min(base_l >> p.cost_shift, SWB_COST_BUCKETS - 1);\n',
+               '    const int key0 = 0;\n')
+  replace_once(files, k, '    if (file0) pos0 = atomicAdd(&p.cost_cnt[cost_row0(p.parity, sh) + key0], 1u);\n',
+               '    if (file0) {\n'
+               '      pos0 = (uint32_t)(env >> 3) * (uint32_t)p.ncg + (uint32_t)l;\n'
+               '      if ((env >> 3) == 0 && l == 0) p.cost_cnt[cost_row0(p.parity, sh)] = (uint32_t)(p.ncg * ((p.N - sh + 7) >> 3));\n'
+               '    }\n')

@@ -39,7 +39,12 @@ def apply(files, arg, replace_once):
                '    unsigned long long* t = p.exp_trace + ((size_t)p.N * p.nbands + (size_t)env * p.nbands + band) * 12;\n'
                '    t[4] = blockIdx.x | ((unsigned long long)(threadIdx.x >> 6) << 32);\n'
                '    t[5] = hdr[SWB_RHDR_GROUPS + g * SWB_RHDR_GSTRIDE];\n'
+               '    t[6] = exp_runs; t[7] = exp_spans;\n'
                '  }\n' + '}\n')
+  replace_once(files, k, '        const int ns = (int)(rec.x >> 24);\n        const swb_i8 ps =',
+               '        const int ns = (int)(rec.x >> 24);\n        exp_runs += 1; exp_spans += (unsigned)ns;\n        const swb_i8 ps =')
+  replace_once(files, k, '  swb_u4 rec = *reinterpret_cast<cptr<swb_u4>>(runs + uo);       // { row',
+               '  unsigned exp_runs = 0, exp_spans = 0;\n  swb_u4 rec = *reinterpret_cast<cptr<swb_u4>>(runs + uo);       // { row')
   h = 'swb.hip'
   replace_once(files, h, 'const char* swb_last_error(void) { return g_err.c_str(); }\n',
                'const char* swb_last_error(void) { return g_err.c_str(); }\n'
