@@ -434,12 +434,16 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   // run lists: 8-byte units per (environment, column group); a canvas row costs 1 unit (one span), 2 (two or three)
   // or more, and rows that repeat the row above cost nothing
   // cost buckets: 32 of them over run lists of up to ~Hc units (longer lists share the last one)
-  p.cost_shift = 0;
-  while ((SWB_COST_BUCKETS << p.cost_shift) < p.Hc) ++p.cost_shift;
+  p.cost_range0 = std::max(8 * p.Hc, SWB_KEY_BUCKETS_FITTED);      // (a run and its units cost 5 .. 9; a launch later the range is a measured one)
   if (!getenv("SWB_NO_COST_ORDER") && p.N < (1 << 24)) {
     p.cost_cap = ((p.Wo + 63) / 64) * ((p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS);
     std::vector<uint32_t> cnt0(5 * SWB_COST_SET + SWB_COST_WORDS, 0u);
     for (int ph = 0; ph < 3; ++ph) cnt0[SWB_COST_WORD_COVER_SHIFT(ph)] = 12;   // bucket width of the cover kernel's cycle counts: 2^12 to begin with
+    for (int par = 0; par < 2; ++par) {                                       // buckets of the second kernel's tasks: [0, cost_range0) to begin with
+      cnt0[SWB_COST_WORD_KEY_LO(par)] = 0u;
+      cnt0[SWB_COST_WORD_KEY_RANGE(par)] = (uint32_t)p.cost_range0;
+      cnt0[SWB_COST_WORD_KEY_SCALE(par)] = (uint32_t)(((unsigned long long)SWB_KEY_BUCKETS_FITTED << 16) / (uint32_t)p.cost_range0);
+    }
     p.prio_div = 4;              // (measured: levels of a quarter of a mean wave 2 % better than of half a wave, at 8192 environments)
     if (const char* x = getenv("SWB_PRIO_DIV")) p.prio_div = std::max(1, atoi(x));
     // (priorities when the launch is at most two rounds of resample waves: in steady state they cost 0.8 %)

@@ -5,7 +5,7 @@ returning atomic at the end of the wave.  Run with SWB_NO_COVER_ORDER=1 (no seco
 
 def apply(files, arg, replace_once):
   k = 'swb_kernels.hip.inc'
-  replace_once(files, k, '    const int key0 = min(base_l >> p.cost_shift, SWB_COST_BUCKETS - 1);\n',
+  replace_once(files, k, '    const int key0 = cost_key(cost_l, (uint32_t)__builtin_amdgcn_readlane((int)filing_words_l, 0), (uint32_t)__builtin_amdgcn_readlane((int)filing_words_l, 1));\n',
                '    const int key0 = 0;\n')
   replace_once(files, k, '    if (file0) pos0 = atomicAdd(&p.cost_cnt[cost_row0(p.parity, sh) + key0], 1u);\n',
                '    if (file0) {\n'
