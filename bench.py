@@ -75,67 +75,119 @@ def profiled_counters(workload, envs, aa, build_id):
   return None
 
 
-def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None, verify=0):
-  """One timed run.  `gate` (N > 1): called after the warm-up, returns False when another rank failed to set up -- then
-  nothing is timed and None is returned (every rank leaves together instead of hanging in the barrier).
-  `verify` > 0: the final state / outputs of that many sampled environments are kept for verify_against_oracle()."""
-  import torch
-  from spriteworld_amd import engine, workloads
-  cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=4, seed=seed, anti_aliasing=aa)
-  eng = engine.Engine(cfg, pool, device=device)
-  rng = np.random.default_rng(2000 + seed)
-  acts_host = [sample(rng) for _ in range(N_ACTION_SETS)]
-  acts = [torch.as_tensor(a, device=eng.device) for a in acts_host]
-  for i in range(warmup):
-    eng.step(acts[i % N_ACTION_SETS])
-  torch.cuda.synchronize(eng.device)
-  if gate is not None and not gate(None):
-    eng.close()
-    return None
-  # from here on every rank runs the same sequence of collectives whatever happens on it: an exception in the timed
-  # region is carried in the result (`error`) instead of being raised past the barrier the other ranks are waiting in
-  run_error = None
-  eng.timing(True)
-  if barrier:
-    barrier()
-  torch.cuda.synchronize(eng.device)
-  t0 = time.perf_counter()
-  try:
-    for i in range(steps):
+class TimedRun(object):
+  """One timed run in three parts, so that several of them can be set up first and then run back to back on the device:
+  build() puts the engine and its action sets on the device; go() does the warm-up steps and times exactly `steps` steps;
+  finish() reads the error flags and (`verify` > 0) the final state / outputs of that many sampled environments for
+  verify_against_oracle(), times the two kernels of a step apart, and closes the engine.
+
+  Timers.  The timed region is bracketed by ONE pair of HIP events on the launch stream (and by the host clock behind a
+  device synchronisation on either side): `kernel_ms` = the events' elapsed time = the kernels of `steps` steps and the
+  gaps between them.  The engine's own timing mode -- three events per step: before the cover kernel, between the two
+  kernels, after the second -- is NOT on in the timed region: measured, its events cost 6 % of a run of back-to-back steps
+  (0.1867 against 0.1758 ms per step at 8192 environments, tools/exp_timing_overhead.py; rounds 1-4 timed with them).  The
+  durations of the two kernels apart come from a short pass in that mode AFTER the timed region (`split`): each carries the
+  cost of its own completion event, as it does under rocprofv3's kernel trace, so their sum exceeds `kernel_ms`."""
+
+  def __init__(self, name, n_envs, steps, warmup, aa, device, seed=0, verify=0):
+    self.name, self.n_envs, self.steps, self.warmup, self.aa, self.device = name, n_envs, steps, warmup, aa, device
+    self.seed, self.verify = seed, verify
+    self.run_error, self.elapsed = None, None
+
+  def build(self):
+    import torch
+    from spriteworld_amd import engine, workloads
+    self.cfg, self.pool, sample = workloads.build(self.name, self.n_envs, episodes_per_env=4, seed=self.seed, anti_aliasing=self.aa)
+    self.eng = engine.Engine(self.cfg, self.pool, device=self.device)
+    rng = np.random.default_rng(2000 + self.seed)
+    self.acts_host = [sample(rng) for _ in range(N_ACTION_SETS)]
+    self.acts = [torch.as_tensor(a, device=self.eng.device) for a in self.acts_host]
+    return self
+
+  def go(self, barrier=None, gate=None):
+    """`gate` (N > 1): called after the warm-up, returns False when another rank failed to set up -- then nothing is timed
+    and False is returned (every rank leaves together instead of hanging in the barrier)."""
+    import torch
+    eng, acts = self.eng, self.acts
+    for i in range(self.warmup):
       eng.step(acts[i % N_ACTION_SETS])
     torch.cuda.synchronize(eng.device)
-  except Exception as e:  # pylint: disable=broad-except
-    run_error = repr(e)
-  if barrier:
-    barrier()
+    if gate is not None and not gate(None):
+      eng.close()
+      return False
+    # from here on every rank runs the same sequence of collectives whatever happens on it: an exception in the timed
+    # region is carried in the result (`error`) instead of being raised past the barrier the other ranks are waiting in
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    self.event_ms = 0.0
+    if barrier:
+      barrier()
     torch.cuda.synchronize(eng.device)
-  elapsed = time.perf_counter() - t0
-  if run_error is not None:
-    return dict(error=run_error, elapsed=elapsed, kernel_ms=0.0, cover_ms=0.0, resample_ms=0.0, launches=0, errors=-1)
-  try:
-    kernel_ms, launches = eng.step_time_ms()
-    cover_ms, resample_ms, _ = eng.kernel_times_ms()
-    eng.timing(False)
-    errors = int(eng.error.max().item())
-    a_bytes = algorithmic_bytes(cfg)
-    variant = eng.variant()
-    sample_out = None
-    if verify:
-      idx = np.sort(np.random.default_rng(99 + seed).choice(n_envs, size=min(verify, n_envs), replace=False))
-      got, st = eng.outputs_host(), eng.state()
-      sample_out = dict(idx=idx, cfg=cfg, pool=pool, warmup=warmup, steps=steps,
-                        actions=[np.ascontiguousarray(a[idx]) for a in acts_host],
-                        got={k: got[k][idx].copy() for k in ('obs', 'reward', 'step_type', 'success', 'discount')},
-                        state={k: st[k][idx].copy() for k in ('x', 'y', 'step_count', 'episode', 'n_sprites')})
-    facts = dict(sprites=cfg.max_sprites, image=[cfg.image_w, cfg.image_h], anti_aliasing=cfg.anti_aliasing,
-                 action_space={0: 'SelectMove', 1: 'DragAndDrop', 2: 'Embodied'}[cfg.action_space],
-                 task={0: 'NoReward', 1: 'FindGoalPosition', 2: 'Clustering'}[cfg.tasks[0].kind] if not cfg.is_meta
-                 else 'MetaAggregated', max_episode_length=cfg.max_episode_length)
-    eng.close()
-  except Exception as e:  # pylint: disable=broad-except
-    return dict(error=repr(e), elapsed=elapsed, kernel_ms=0.0, cover_ms=0.0, resample_ms=0.0, launches=0, errors=-1)
-  return dict(elapsed=elapsed, kernel_ms=kernel_ms, cover_ms=cover_ms, resample_ms=resample_ms, launches=launches,
-              a_bytes=a_bytes, errors=errors, variant=variant, facts=facts, sample=sample_out, error=None)
+    t0 = time.perf_counter()
+    try:
+      ev0.record()                                   # (torch's current stream: the one the engine launches on)
+      for i in range(self.steps):
+        eng.step(acts[i % N_ACTION_SETS])
+      ev1.record()
+      torch.cuda.synchronize(eng.device)
+      self.event_ms = float(ev0.elapsed_time(ev1))
+    except Exception as e:  # pylint: disable=broad-except
+      self.run_error = repr(e)
+    if barrier:
+      barrier()
+      torch.cuda.synchronize(eng.device)
+    self.elapsed = time.perf_counter() - t0
+    return True
+
+  def finish(self):
+    eng, cfg, elapsed = self.eng, self.cfg, self.elapsed
+    if self.run_error is not None:
+      return dict(error=self.run_error, elapsed=elapsed, kernel_ms=0.0, cover_ms=0.0, resample_ms=0.0, launches=0, errors=-1)
+    try:
+      import torch
+      kernel_ms, launches = self.event_ms, self.steps
+      errors = int(eng.error.max().item())
+      a_bytes = algorithmic_bytes(cfg)
+      variant = eng.variant()
+      sample_out = None
+      if self.verify:
+        idx = np.sort(np.random.default_rng(99 + self.seed).choice(self.n_envs, size=min(self.verify, self.n_envs), replace=False))
+        got, st = eng.outputs_host(), eng.state()
+        sample_out = dict(idx=idx, cfg=cfg, pool=self.pool, warmup=self.warmup, steps=self.steps,
+                          actions=[np.ascontiguousarray(a[idx]) for a in self.acts_host],
+                          got={k: got[k][idx].copy() for k in ('obs', 'reward', 'step_type', 'success', 'discount')},
+                          state={k: st[k][idx].copy() for k in ('x', 'y', 'step_count', 'episode', 'n_sprites')})
+      # the two kernels apart: a pass in the engine's timing mode behind the timed region (its state is no longer needed)
+      split_steps = max(10, min(self.steps, 40))
+      eng.timing(True)
+      for i in range(split_steps):
+        eng.step(self.acts[i % N_ACTION_SETS])
+      torch.cuda.synchronize(eng.device)
+      split_total, k = eng.step_time_ms()
+      split_cover, split_second, _ = eng.kernel_times_ms()
+      eng.timing(False)
+      cover_ms, resample_ms = split_cover / max(k, 1) * launches, split_second / max(k, 1) * launches     # (per step x launches)
+      split = dict(steps=int(k), step_ms=split_total / max(k, 1), cover_ms=split_cover / max(k, 1), second_ms=split_second / max(k, 1))
+      errors = max(errors, int(eng.error.max().item()))
+      facts = dict(sprites=cfg.max_sprites, image=[cfg.image_w, cfg.image_h], anti_aliasing=cfg.anti_aliasing,
+                   action_space={0: 'SelectMove', 1: 'DragAndDrop', 2: 'Embodied'}[cfg.action_space],
+                   task={0: 'NoReward', 1: 'FindGoalPosition', 2: 'Clustering'}[cfg.tasks[0].kind] if not cfg.is_meta
+                   else 'MetaAggregated', max_episode_length=cfg.max_episode_length)
+      eng.close()
+    except Exception as e:  # pylint: disable=broad-except
+      return dict(error=repr(e), elapsed=elapsed, kernel_ms=0.0, cover_ms=0.0, resample_ms=0.0, launches=0, errors=-1)
+    return dict(elapsed=elapsed, kernel_ms=kernel_ms, cover_ms=cover_ms, resample_ms=resample_ms, launches=launches,
+                a_bytes=a_bytes, errors=errors, variant=variant, facts=facts, sample=sample_out, error=None, split=split)
+
+
+def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None, verify=0, before=None):
+  """One timed run, start to end.  `before`: called once the engine and its action sets are on the device, before the first
+  warm-up step (the `extra` runs of the default line: see main()).  Returns None when the gate closed."""
+  run = TimedRun(name, n_envs, steps, warmup, aa, device, seed=seed, verify=verify).build()
+  if before is not None:
+    before()
+  if not run.go(barrier=barrier, gate=gate):
+    return None
+  return run.finish()
 
 
 def verify_against_oracle(sample):
@@ -178,35 +230,52 @@ def verify_against_oracle(sample):
           'checker': 'oracle/sw_oracle.c through the same actions, after the timed region (%.1f s)' % (time.perf_counter() - t0)}
 
 
-def gpu_run_groups(name, n_envs, groups, steps, warmup, aa, device):
-  """The same batch as `groups` independent engines stepped on `groups` HIP streams (no cross-group
-  ordering between steps): the double-buffered stepping pattern of RL samplers.  Returns env-steps/s."""
-  import torch
-  from spriteworld_amd import engine, workloads
-  n = n_envs // groups
-  engs, acts, streams = [], [], []
-  for g in range(groups):
-    cfg, pool, sample = workloads.build(name, n, episodes_per_env=4, seed=g, anti_aliasing=aa)
-    engs.append(engine.Engine(cfg, pool, device=device))
-    rng = np.random.default_rng(2000 + g)
-    acts.append([torch.as_tensor(sample(rng), device=engs[g].device) for _ in range(N_ACTION_SETS)])
-    streams.append(torch.cuda.Stream(device=engs[g].device))
+class GroupsRun(object):
+  """The same batch as `groups` independent engines stepped on `groups` HIP streams (no cross-group ordering between
+  steps): the double-buffered stepping pattern of RL samplers.  build(), then go() -> (env-steps/s, error flags)."""
 
-  def run(k):
-    for i in range(k):
-      for g in range(groups):
-        with torch.cuda.stream(streams[g]):
-          engs[g].step(acts[g][i % N_ACTION_SETS])
-  run(warmup)
-  torch.cuda.synchronize(engs[0].device)
-  t0 = time.perf_counter()
-  run(steps)
-  torch.cuda.synchronize(engs[0].device)
-  elapsed = time.perf_counter() - t0
-  errors = max(int(e.error.max().item()) for e in engs)
-  for e in engs:
-    e.close()
-  return n * groups * steps / elapsed, errors
+  def __init__(self, name, n_envs, groups, steps, warmup, aa, device):
+    self.name, self.n, self.groups, self.steps, self.warmup, self.aa, self.device = name, n_envs // groups, groups, steps, warmup, aa, device
+
+  def build(self):
+    import torch
+    from spriteworld_amd import engine, workloads
+    self.engs, self.acts, self.streams = [], [], []
+    for g in range(self.groups):
+      cfg, pool, sample = workloads.build(self.name, self.n, episodes_per_env=4, seed=g, anti_aliasing=self.aa)
+      self.engs.append(engine.Engine(cfg, pool, device=self.device))
+      rng = np.random.default_rng(2000 + g)
+      self.acts.append([torch.as_tensor(sample(rng), device=self.engs[g].device) for _ in range(N_ACTION_SETS)])
+      self.streams.append(torch.cuda.Stream(device=self.engs[g].device))
+    return self
+
+  def go(self):
+    import torch
+    engs, acts, streams = self.engs, self.acts, self.streams
+
+    def run(k):
+      for i in range(k):
+        for g in range(self.groups):
+          with torch.cuda.stream(streams[g]):
+            engs[g].step(acts[g][i % N_ACTION_SETS])
+    run(self.warmup)
+    torch.cuda.synchronize(engs[0].device)
+    t0 = time.perf_counter()
+    run(self.steps)
+    torch.cuda.synchronize(engs[0].device)
+    self.elapsed = time.perf_counter() - t0
+
+  def finish(self):
+    errors = max(int(e.error.max().item()) for e in self.engs)
+    for e in self.engs:
+      e.close()
+    return self.n * self.groups * self.steps / self.elapsed, errors
+
+
+def gpu_run_groups(name, n_envs, groups, steps, warmup, aa, device):
+  run = GroupsRun(name, n_envs, groups, steps, warmup, aa, device).build()
+  run.go()
+  return run.finish()
 
 
 def usable_cores():
@@ -334,8 +403,13 @@ def assemble_line(args, res, elapsed):
       'traffic': counters['hbm_traffic_bytes_per_launch'] if counters else None,
       'kernel': ('%s + %s' % (first, second)) if not second.startswith('none') else first + ' (paints the frame: anti_aliasing = 1)',
       'kernel_ms': kernel_s * 1e3,
+      'kernel_ms_source': 'one pair of HIP events on the launch stream around the timed steps / steps',
       'algorithmic_bytes_per_env_step': res['a_bytes'],
-      # each kernel on its own: the second one writes the frames (98.6 % of the algorithmic bytes)
+      # each kernel on its own (the second one writes the frames, 98.6 % of the algorithmic bytes): per-step events of a
+      # separate pass behind the timed region -- every kernel then carries its own completion event, as under rocprofv3's
+      # kernel trace, and their sum exceeds kernel_ms (TimedRun)
+      'kernels_source': ('engine timing mode, %d steps after the timed region (step %.4f ms with its three events)' %
+                         (res['split']['steps'], res['split']['step_ms'])) if res.get('split') else 'engine timing mode',
       'kernels': [
           {'name': first, 'ms': cover_s * 1e3, 'waves_per_simd': variant['waves_per_simd'],
            'lds_bytes_per_wave': variant['lds_bytes_per_wave']},
@@ -452,6 +526,50 @@ def main():
     setup_errors[:] = [(r, e) for r, e in enumerate(status) if e is not None]
     return not setup_errors
 
+  # The `extra` workloads of the default N = 1 line run BEFORE the headline's warm-up and timed steps, not after them, and every
+  # engine of the line is built before the first of them runs, so that the device goes from one timed loop to the next without
+  # idling in between.  A device that comes out of idle raises its clocks over tens of milliseconds of load
+  # (profiles/r04_launch_convergence.json: a compute-bound control kernel drifts 7 % over its first 64 launches) and drops them
+  # again within milliseconds of idling; the driver's 5 + 20 steps are 5 ms -- timed first, the headline is timed on the ramp
+  # and everything after it at speed.  The timed region itself is unchanged: exactly --warmup untimed steps, then exactly
+  # --steps timed ones.
+  extra = {}
+  extra_runs = []
+
+  def build_extras():
+    short = max(args.steps // 4, 10)
+    for label, (nm, n, aa) in {
+        'cluster_s5_aa1': ('cluster_s5', args.envs_per_gpu, 1),
+        'goal_s5_1024_aa5': ('goal_s5', 1024, 5),
+        'embodied_s12_128_aa5': ('embodied_s12', args.envs_per_gpu, 5),
+        # BASELINE configs[3]'s per-GPU share is 8192; this is the same scene with 8x the batch in ONE launch
+        # (the launch's fixed fill/drain cost amortised, DESIGN.md section 3)
+        'cluster_s5_65536_aa5': ('cluster_s5', 65536, 5),
+    }.items():
+      extra_runs.append((label, TimedRun(nm, n, short, 5, aa, device).build()))
+    # the headline batch as two groups of 4096 on two HIP streams: consecutive steps of different groups overlap,
+    # which hides the fill/drain of each launch (an application-level choice; `value` is one launch per step)
+    extra_runs.append(('%s_2_groups_2_streams' % args.workload, GroupsRun(args.workload, args.envs_per_gpu, 2, short, 5, args.aa, device).build()))
+
+  def run_extras():
+    build_extras()
+    for _, run in extra_runs:
+      run.go()
+
+  def finish_extras():
+    for label, run in extra_runs:
+      if isinstance(run, GroupsRun):
+        rate, errs = run.finish()
+        extra[label] = {'env_steps_per_s': rate, 'env_errors': errs}
+        continue
+      r = run.finish()
+      n, short = run.n_envs, run.steps
+      ks = r['kernel_ms'] / 1e3 / max(r['launches'], 1)
+      extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel': r['variant']['kernel'], 'kernel_ms': ks * 1e3,
+                      'cover_ms': r['cover_ms'] / max(r['launches'], 1), 'resample_ms': r['resample_ms'] / max(r['launches'], 1),
+                      'hbm_GBs': r['a_bytes'] * n / ks / 1e9, 'hbm_frac': r['a_bytes'] * n / ks / 1e9 / HBM_PEAK_GBS,
+                      'env_errors': r['errors']}
+
   res = None
   gated = [False]                            # this rank has been through the gate (set by the wrapper below)
 
@@ -462,7 +580,8 @@ def main():
   try:
     res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
                   barrier=barrier, seed=rank, gate=gate_once if dist is not None else None,
-                  verify=64 if (rank == 0 and not args.no_verify) else 0)
+                  verify=64 if (rank == 0 and not args.no_verify) else 0,
+                  before=run_extras if (args.gpus == 1 and dist is None and not args.no_extra) else None)
   except Exception as e:  # pylint: disable=broad-except
     if dist is None:
       raise
@@ -526,28 +645,10 @@ def main():
     out['per_rank'] = per_rank
   if gather is not None:
     out['obs_allgather'] = gather
-  if args.gpus == 1 and not args.no_extra:
-    extra = {}
-    short = max(args.steps // 4, 10)
-    for label, (nm, n, aa) in {
-        'cluster_s5_aa1': ('cluster_s5', args.envs_per_gpu, 1),
-        'goal_s5_1024_aa5': ('goal_s5', 1024, 5),
-        'embodied_s12_128_aa5': ('embodied_s12', args.envs_per_gpu, 5),
-        # BASELINE configs[3]'s per-GPU share is 8192; this is the same scene with 8x the batch in ONE launch
-        # (the launch's fixed fill/drain cost amortised, DESIGN.md section 3)
-        'cluster_s5_65536_aa5': ('cluster_s5', 65536, 5),
-    }.items():
-      r = gpu_run(nm, n, short, 5, aa, device)
-      ks = r['kernel_ms'] / 1e3 / max(r['launches'], 1)
-      extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel': r['variant']['kernel'], 'kernel_ms': ks * 1e3,
-                      'cover_ms': r['cover_ms'] / max(r['launches'], 1), 'resample_ms': r['resample_ms'] / max(r['launches'], 1),
-                      'hbm_GBs': r['a_bytes'] * n / ks / 1e9, 'hbm_frac': r['a_bytes'] * n / ks / 1e9 / HBM_PEAK_GBS,
-                      'env_errors': r['errors']}
-    # the headline batch as two groups of 4096 on two HIP streams: consecutive steps of different groups overlap,
-    # which hides the fill/drain of each launch (an application-level choice; `value` above is one launch per step)
-    rate, errs = gpu_run_groups(args.workload, args.envs_per_gpu, 2, short, 5, args.aa, device)
-    extra['%s_2_groups_2_streams' % args.workload] = {'env_steps_per_s': rate, 'env_errors': errs}
+  if extra_runs:
+    finish_extras()
     out['extra'] = extra
+    out['order'] = 'the extra workloads ran before the warm-up and timed steps of this line (device at its working clocks)'
   if args.gpus == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(args.workload, args.aa)
   print(json.dumps(out))
