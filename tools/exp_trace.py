@@ -23,6 +23,9 @@ def pct(a, qs=(0, 5, 25, 50, 75, 95, 99, 100)):
 def timeline(t, label):
   rt0, rt1, cyc, hw = [t[:, i] for i in range(4)]
   ok = rt1 > 0
+  if not ok.any():                                  # (no second kernel: anti_aliasing = 1 painted by the cover kernel)
+    print(label, 'no waves recorded', flush=True)
+    return {'waves': 0}
   rt0, rt1, cyc, hw = rt0[ok], rt1[ok], cyc[ok], hw[ok]
   t0 = rt0.min()
   start_us, end_us = (rt0 - t0) / 100.0, (rt1 - t0) / 100.0
