@@ -431,18 +431,30 @@ def test_refresh_pool_redraws_everything_but_the_live_entries():
 
 
 @pytest.mark.gpu
-def test_refresh_every_keeps_episodes_fresh():
-  """With refresh_every the same (env, pool slot) never serves the same episode twice."""
+@pytest.mark.parametrize('refresh_every,early_ends', [(5, False), ('auto', True)])
+def test_refresh_every_keeps_episodes_fresh(refresh_every, early_ends):
+  """With refresh_every the same (env, pool slot) never serves the same episode twice.  refresh_every = 5 with episodes that
+  always last their 5 steps (FIRST + max_episode_length = 4; the task cannot succeed): the pool is redrawn right after every
+  LAST step.  'auto' (every 2 * (episodes_per_env - 1) = 2 steps) gives the guarantee whatever ends an episode early -- here a
+  task that succeeds now and then.  (Until round 5 the first case ran with the succeeding task: a single early success within
+  the 40 steps made an environment wrap to an entry not yet redrawn, and the test failed once in a while.)"""
   from spriteworld_amd import environment
+  np.random.seed(11)
   sampler, task, rend = _cobra_like()
+  if not early_ends:
+    task = tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.4), terminate_distance=1e-9)
+  else:
+    task = tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.4), terminate_distance=0.45)
   env = environment.BatchedEnvironment(task=task, action_space=action_spaces.SelectMove(scale=0.25), renderers=rend,
                                        init_sprites=sampler, max_episode_length=4, num_envs=32, episodes_per_env=2,
-                                       refresh_every=5)
+                                       refresh_every=refresh_every)
   env.reset()
   seen = set()
+  lasts = 0
   for _ in range(40):
     ts = env.step(env.sample_actions())
     first = (ts.step_type == 0).cpu().numpy()
+    lasts += int((ts.step_type == 2).sum().item())
     if first.any():
       st = env.state()
       for e in np.flatnonzero(first):
@@ -450,6 +462,8 @@ def test_refresh_every_keeps_episodes_fresh():
         assert key not in seen
         seen.add(key)
   assert len(seen) > 32 * 4
+  if early_ends:
+    assert lasts > 32 * 40 // 5 + 16                          # episodes did end before their fifth step
   env.check()
   env.close()
 
