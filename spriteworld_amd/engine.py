@@ -216,6 +216,10 @@ class Engine(object):
     return d
 
   def timing(self, enable):
+    """Three HIP events per step (before the cover kernel, between the two kernels, after the second): `step_time_ms()` /
+    `kernel_times_ms()` read them.  A diagnostic: each event is a completion signal the device has to raise between two
+    kernels that would otherwise follow each other directly -- measured, a run of back-to-back steps is 6 % slower with
+    them (tools/exp_timing_overhead.py), so time a run with ONE pair of events around it and use this mode for the split."""
     _lib.check(self.lib.swb_timing_enable(self._h, int(enable)))
 
   def step_time_ms(self):

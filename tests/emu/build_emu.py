@@ -79,7 +79,7 @@ def _instrument(text):
   after('    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)sp_a, s);', hook('p2_sprite_passes'))
   after('  rs.cnt = 0; rs.s0 = rs.s1 = rs.s2 = 0u;', hook('p2_batches'))
   after('        for (int e = 0; e < ne; ++e) {', hook('p2_edge_iterations'))
-  after('        for (int j = 0; j < bound; j += G) {', hook('p2_edge_iterations'))
+  after('          for (int j = 0; j < bound; j += G) {', hook('p2_edge_iterations'), count=2)      # (the loop exists unswitched: two copies)
   after('    const int total = __builtin_amdgcn_readlane(incl, SWB_WAVE - 1);', hook('run_units', 'total'))
   anchor = '        auto take = [&]() __attribute__((always_inline)) {'
   assert text.count(anchor) == 1, anchor

@@ -39,3 +39,13 @@ def test_every_overlay_file_is_listed():
   names = {os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, 'tools', 'overlays')) if f.endswith('.py')}
   listed = {o.split(':')[0] for group in OVERLAYS for o in group}
   assert names == listed, names ^ listed
+
+
+def test_event_counters_of_the_emulated_build_still_anchor():
+  """tools/emu_stats.py (the exact event counts behind the resample cost model, tools/assemble_evidence.py) instruments the kernel
+  source at anchor lines (tests/emu/build_emu.py): they must all still be there."""
+  sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+  import build_emu
+  with open(os.path.join(ROOT, 'spriteworld_amd', 'csrc', 'swb_kernels.hip.inc')) as f:
+    text = f.read()
+  assert 'emu_count(' in build_emu._instrument(text)
