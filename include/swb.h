@@ -362,15 +362,18 @@ typedef struct swb_variant_info {
   int32_t resample_waves_per_simd; /* ... the resample / fill kernel */
   int32_t n_bands;            /* bands of output rows: waves of the second kernel per (environment, column group) */
   int32_t n_column_groups;    /* groups of 64 output columns */
-  int32_t run_cap;            /* capacity of a run list (8-byte units per environment and column group) */
+  int32_t run_cap;            /* capacity of a run list (8-byte units per environment and column group): max(4, max_sprites + 1)
+                               * per canvas row -- any scene of convex sprites fits; a list that overflows flags its environment */
   int32_t paint_in_cover;     /* 1: anti_aliasing = 1 and an image of up to 64 columns -- the cover kernel writes the frame
                                * itself and no second kernel is launched */
 } swb_variant_info;
 int swb_variant(swb_handle h, swb_variant_info* out);
 const char* swb_build_id(void);
 
-/* Kernel timing: HIP events recorded on `stream` around every swb_step launch
- * while enabled; swb_step_time_ms returns (total ms, launches) since enable. */
+/* Kernel timing: three HIP events recorded on `stream` per swb_step launch while enabled (before the cover kernel, between the
+ * two kernels, after the second); swb_step_time_ms returns (total ms, launches) since enable.  A diagnostic: every event is a
+ * completion signal between two kernels that would otherwise follow each other directly -- measured on MI355X, a run of
+ * back-to-back steps is 6 % slower with it on.  To time a run, bracket it with ONE pair of events of your own. */
 int swb_timing_enable(swb_handle h, int32_t enable);
 int swb_step_time_ms(swb_handle h, double* total_ms, int64_t* launches);
 /* The same interval split at the event between the two kernels of a step: cover (state, geometry,

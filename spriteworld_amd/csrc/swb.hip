@@ -474,7 +474,13 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
       while ((1 << p.deal_shift) < per_xcd) ++p.deal_shift;
     if (const char* x = getenv("SWB_DEAL_SHIFT")) p.deal_shift = std::max(0, atoi(x));      // tests: short rounds on small batches
   }
-  p.run_cap = 4 * p.Hc;
+  // Capacity of a run list in 8-byte units.  A canvas row of s >= 2 visible spans costs 1 + s / 2 units and S convex sprites
+  // leave at most 2 S - 1 spans in a row: (S + 1) units per row hold any scene of convex sprites even if no two rows fold
+  // into a run (the usual scene needs a seventh of that).  Until round 5 the capacity was 4 rows' worth whatever S: ten
+  // sprites on a 60-row canvas overflowed it (seed 2681 of tools/fuzz_sweep.py: the environment flagged, its frame short of a
+  // batch of rows).  Non-convex sprites can exceed any such bound in principle; a list that still overflows flags its
+  // environment (SWB_ENV_ERR_SPAN_OVERFLOW).
+  p.run_cap = std::max(4, p.S + 1) * p.Hc + 1;
   if (const char* x = getenv("SWB_RUN_CAP")) p.run_cap = std::max(8, atoi(x));      // tests
   const size_t NS = (size_t)p.N * p.S;
   int rc = 0;

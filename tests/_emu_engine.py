@@ -7,6 +7,7 @@ test suite can execute the kernel source itself against the oracle where no GPU 
 loads it (spriteworld_amd/_lib.py loads csrc/libswb.so, built by hipcc for gfx950, and raises when it is missing).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -39,7 +40,8 @@ def lib():
     l.swb_reset_all.argtypes = [C.c_void_p, C.c_void_p]
     l.swb_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_abi.SwbOutputs), C.c_void_p]
     l.swb_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    l.swb_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(l, 'swb_evaluate') or not os.environ.get('SWB_EMU_CSRC'):      # (an older copy of the sources may lack it)
+      l.swb_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     l.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     l.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
     l.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

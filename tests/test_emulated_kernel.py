@@ -93,6 +93,14 @@ def test_emulated_kernel_randomised_configurations(seed):
   _run('fuzz_%d' % seed, 3, 3, 5, seed=seed)
 
 
+def test_emulated_run_list_capacity_follows_the_sprite_count():
+  """Ten sprites on a 60-row canvas (192 x 60 at anti_aliasing = 3; seed 2681 of tools/fuzz_sweep.py, found in round 5): rows of
+  four to eight visible spans, 241 .. 300 units of run list for 60 rows -- the capacity was 4 units per canvas row whatever the
+  sprite count, the environment was flagged SWB_ENV_ERR_SPAN_OVERFLOW at step 7 and its frame was short of a batch of rows.
+  Now (S + 1) units per row: any scene of convex sprites, folded or not."""
+  _run('fuzz_2681', 64, 8, 5, seed=2681)
+
+
 @pytest.mark.parametrize('name,n_envs,aa', [('embodied_s12', 2, 5), ('ragged_s16', 6, 5), ('cluster_s5', 3, 1)])
 def test_emulated_kernel_span_overflow_slots(monkeypatch, name, n_envs, aa):
   """Rows with more than three visible spans take the HBM overflow path when the LDS lists are switched off."""

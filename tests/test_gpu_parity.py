@@ -116,6 +116,12 @@ def test_shapes_of_33_to_64_edges(n_vertices, name, aa):
     _run(name, 128, 8, aa)
 
 
+def test_ten_sprites_on_a_sixty_row_canvas_fit_their_run_lists():
+  """Seed 2681 of tools/fuzz_sweep.py: the run-list capacity follows the sprite count (round 5; it was 4 units per canvas row and
+  this scene, 4 - 8 visible spans in most rows, overflowed it: flagged, frame short of a batch of rows)."""
+  _run('fuzz_2681', 64, 10, 5, seed=2681)
+
+
 def test_tiny_sprites_degenerate_polygons():
   _run('tiny_s6', 256, 10, 5)
 
