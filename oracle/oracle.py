@@ -21,14 +21,22 @@ _lib = None
 
 
 def build(force=False):
-  """Compiles the oracle with gcc (no-op when up to date)."""
+  """Compiles the oracle with gcc (no-op when up to date).  An exclusive file lock makes concurrent callers (pytest-xdist workers
+  right after a source change) wait for one build instead of loading a library another process is still writing."""
+  import fcntl
   src = os.path.join(_HERE, 'sw_oracle.c')
   hdr = os.path.join(_HERE, '..', 'include', 'swb.h')
-  if (not force and os.path.exists(_LIB_PATH) and
-      os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+
+  def fresh():
+    return (os.path.exists(_LIB_PATH) and
+            os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)))
+  if not force and fresh():
     return _LIB_PATH
-  subprocess.check_call(['make', '-C', _HERE, '-B' if force else '-s'],
-                        stdout=subprocess.DEVNULL)
+  os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
+  with open(os.path.join(os.path.dirname(_LIB_PATH), '.lock'), 'w') as lock:
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    if force or not fresh():
+      subprocess.check_call(['make', '-C', _HERE, '-B' if force else '-s'], stdout=subprocess.DEVNULL)
   return _LIB_PATH
 
 
