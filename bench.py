@@ -551,10 +551,17 @@ def main():
     # which hides the fill/drain of each launch (an application-level choice; `value` is one launch per step)
     extra_runs.append(('%s_2_groups_2_streams' % args.workload, GroupsRun(args.workload, args.envs_per_gpu, 2, short, 5, args.aa, device).build()))
 
+  extra_error = []
+
   def run_extras():
-    build_extras()
-    for _, run in extra_runs:
-      run.go()
+    # (a failure here must not cost the line its headline: it is recorded and the extras are dropped)
+    try:
+      build_extras()
+      for _, run in extra_runs:
+        run.go()
+    except Exception as e:  # pylint: disable=broad-except
+      extra_error.append(repr(e))
+      del extra_runs[:]
 
   def finish_extras():
     for label, run in extra_runs:
@@ -645,8 +652,13 @@ def main():
     out['per_rank'] = per_rank
   if gather is not None:
     out['obs_allgather'] = gather
+  if extra_error:
+    out['extra_error'] = extra_error[0]
   if extra_runs:
-    finish_extras()
+    try:
+      finish_extras()
+    except Exception as e:  # pylint: disable=broad-except
+      out['extra_error'] = repr(e)
     out['extra'] = extra
     out['order'] = 'the extra workloads ran before the warm-up and timed steps of this line (device at its working clocks)'
   if args.gpus == 1 and not args.no_cpu_baseline:
