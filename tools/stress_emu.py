@@ -4,7 +4,7 @@ reach: 8 .. 16 sprites, mostly non-convex shapes, scales up to 1.5 (sprites larg
 and extreme canvases, anti_aliasing 1 .. 8.  Per seed: 8 environments x 4 steps.  Outcomes: `ok` (everything bit-exact, no flag),
 `flagged` (the engine flagged an environment SWB_ENV_ERR_SPAN_OVERFLOW -- a capacity limit, never silent: counted, and every
 environment that is NOT flagged must still be exact), `MISMATCH` (a difference without a flag: a bug).
-usage: python tools/stress_emu.py FIRST LAST [PROCESSES] [--dense]
+usage: python tools/stress_emu.py FIRST LAST [PROCESSES] [--dense | --row] [--tasks]
 --dense: 16 spoked / starred sprites of scale 0.6 .. 1.0 piled on the middle of the frame (dozens of spans per canvas row: the
 span lists' and run lists' capacities)."""
 import os
@@ -16,6 +16,7 @@ import numpy as np  # noqa: E402
 
 
 DENSE = '--dense' in sys.argv
+TASKS = '--tasks' in sys.argv      # Clustering (2 .. 8 clusters) / MetaAggregated / DragAndDrop / float64 positions / velocities too
 ROW = '--row' in sys.argv          # 16 small spoked sprites side by side on the same canvas rows of a wide image: more visible spans
                                    # per row than the span lists / run lists hold -- the overflow must be FLAGGED, never silent
 
@@ -42,21 +43,53 @@ def build(seed, n_envs):
     S, w, h, aa = 16, 256, int(4 * r.integers(2, 9)), 2
     shape_names = tuple(r.choice(['spoke_6', 'star_6', 'spoke_5', 'spoke_4'], size=2, replace=False))
     scales = (0.05, 0.06, 0.04)
-  task = tasks.FindGoalPosition(filter_distrib=None, goal_position=(0.5, 0.5), terminate_distance=float(r.uniform(0.02, 0.2)))
-  labels = [[int(r.integers(0, 2))] for _ in range(S)]
-  aspace = action_spaces.Embodied(step_size=0.1) if r.integers(0, 3) == 0 else action_spaces.SelectMove(scale=0.5)
+  kind = int(r.integers(0, 3)) if TASKS else 0
+  n_tasks, full = 1, False
+  if kind == 0:
+    task = tasks.FindGoalPosition(filter_distrib=None, goal_position=(0.5, 0.5), terminate_distance=float(r.uniform(0.02, 0.2)))
+    labels = [[int(r.integers(0, 2))] for _ in range(S)]
+  elif kind == 1:                                   # Clustering with 2 .. 8 clusters (Davies-Bouldin needs 2 <= k < members)
+    k = int(r.integers(2, min(9, S // 2 + 1)))
+    task = tasks.Clustering([None] * k, termination_threshold=float(r.uniform(1.0, 3.0)), terminate_bonus=float(r.integers(0, 2)),
+                            sparse_reward=bool(r.integers(0, 2)), reward_range=float(r.integers(1, 12)))
+    labels = [[c % k] for c in range(2 * k)] + [[int(r.integers(-1, k))] for _ in range(S - 2 * k)]
+    full = True
+  else:                                             # MetaAggregated over three goal tasks
+    subs = [tasks.FindGoalPosition(filter_distrib=None, goal_position=(0.25 + 0.5 * (i % 2), 0.25 + 0.5 * (i // 2)),
+                                   terminate_distance=0.2, raw_reward_multiplier=10.) for i in range(3)]
+    task = tasks.MetaAggregated(subs, reward_aggregator=str(r.choice(['sum', 'max', 'min', 'mean'])),
+                                termination_criterion=str(r.choice(['all', 'any'])), terminate_bonus=float(r.integers(0, 2)))
+    labels = [[int(i % 3 == t) for t in range(3)] for i in range(S)]
+    n_tasks = 3
+  pick = int(r.integers(0, 3))
+  aspace = (action_spaces.Embodied(step_size=0.1, motion_cost=float(r.choice([0.0, 0.4]))) if pick == 0 else
+            action_spaces.SelectMove(scale=0.5, motion_cost=float(r.choice([0.0, 0.7]))) if pick == 1 or not TASKS else
+            action_spaces.DragAndDrop(scale=0.5, motion_cost=float(r.choice([0.0, 1.3]))))
   rend = {'image': renderers.PILRenderer(image_size=(w, h), anti_aliasing=aa,
                                          bg_color=tuple(int(v) for v in (r.integers(0, 256, 3) * r.integers(0, 2))),
                                          color_to_rgb=renderers.hsv_to_rgb)}
   P = n_envs * 2
-  pool = synthetic.make_pool(r, P, S, [(0.0, 1.0)] * S, labels, shape_names=shape_names, scales=scales, angles=angles,
+  pool = synthetic.make_pool(r, P, S, [(0.0, 1.0)] * S, labels, n_tasks=n_tasks, shape_names=shape_names, scales=scales, angles=angles,
                              xy_range=(0.3, 0.7) if DENSE else ((-0.3, 1.3) if not keep else (0.0, 1.0)))
   pool.n_sprites[:] = S if (DENSE or ROW) else np.maximum(r.integers(S // 2, S + 1, size=P), 1)
   if ROW:
     pool.y[:] = 0.5 + r.uniform(-0.02, 0.02, size=pool.y.shape).astype(np.float32)
     pool.x[:] = ((np.arange(S)[None, :] + 0.5) / S + r.uniform(-0.01, 0.01, size=pool.x.shape)).astype(np.float32)
+  f32_pos = True
+  if TASKS:
+    if full:
+      pool.n_sprites[:] = S
+    f32_pos = bool(r.integers(0, 2))
+    if not f32_pos:
+      pool.x[:] = r.uniform(0.0, 1.0, size=pool.x.shape)
+      pool.y[:] = r.uniform(0.0, 1.0, size=pool.y.shape)
+    if r.integers(0, 2):
+      vel = r.uniform(-0.03, 0.03, size=(2,) + pool.x.shape)
+      if f32_pos:
+        vel = vel.astype(np.float32).astype(np.float64)
+      pool.x_vel[:], pool.y_vel[:] = vel[0], vel[1]
   pool.assign_round_robin(n_envs, 2)
-  cfg = lowering.lower_config(task, aspace, rend, keep, 6, n_envs, S, True)
+  cfg = lowering.lower_config(task, aspace, rend, keep, 6, n_envs, S, f32_pos)
 
   def sample(rng):
     if cfg.action_space == 2:
@@ -83,7 +116,10 @@ def one(seed):
       other = (got['error'] & ~np.uint8(4)) != (want['error'] & ~np.uint8(4))
       ok = ~flagged
       st_g, st_o = eng.state(), ora.state()
-      bad = other[ok].any() or not np.array_equal(got['obs'][ok], want['obs'][ok]) or \
+      rg, ro = got['reward'][ok], want['reward'][ok]
+      rew_bad = not (np.array_equal(np.isnan(rg), np.isnan(ro)) and np.array_equal(rg[~np.isnan(rg)].view(np.uint64), ro[~np.isnan(ro)].view(np.uint64)))
+      bad = rew_bad or not np.array_equal(got['success'][ok], want['success'][ok]) or \
+          other[ok].any() or not np.array_equal(got['obs'][ok], want['obs'][ok]) or \
           not np.array_equal(st_g['x'][ok].view(np.uint64), st_o['x'][ok].view(np.uint64)) or \
           not np.array_equal(got['step_type'][ok], want['step_type'][ok])
       if bad:
