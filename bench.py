@@ -60,19 +60,23 @@ VALU_CYCLES_PER_INST = 4.24      # profiles/r02_ubench_valu.md + SQ_ACTIVE_INST_
 
 def profiled_counters(workload, envs, aa, build_id):
   """PMC figures of the committed rocprofv3 passes (profiles/rNN_counters.json, newest round first) for this exact build and
-  workload.
+  workload -> (record or None, state).
 
   bench.py cannot collect PMC counters itself.  A file records the build id (content hash of the kernel sources) its passes
-  ran on; for any other build, workload or batch the figures are stale and None is returned."""
+  ran on.  state: 'fresh' -- a record of exactly this build; 'stale' -- the newest record of this workload is of ANOTHER
+  build (a kernel edit without a re-run of tools/final_evidence.sh): the line then says so instead of quoting it or
+  silently dropping the block; 'none' -- no committed passes for this workload at all."""
   import glob
+  state = 'none'
   for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_counters.json')), reverse=True):
     with open(path) as f:
       data = json.load(f)
     for rec in data.get('records', []):
-      if (rec['build_id'] == build_id and rec['workload'] == workload and rec['envs'] == envs and
-          rec['anti_aliasing'] == aa):
-        return rec
-  return None
+      if rec['workload'] == workload and rec['envs'] == envs and rec['anti_aliasing'] == aa:
+        if rec['build_id'] == build_id:
+          return rec, 'fresh'
+        state = 'stale'
+  return None, state
 
 
 class TimedRun(object):
@@ -137,6 +141,25 @@ class TimedRun(object):
       torch.cuda.synchronize(eng.device)
     self.elapsed = time.perf_counter() - t0
     return True
+
+  def ramp(self, ms):
+    """Keeps the device busy with this engine's steps for `ms` milliseconds (untimed); returns the steps taken."""
+    import torch
+    t0, k = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+      for _ in range(16):
+        self.eng.step(self.acts[k % N_ACTION_SETS])
+        k += 1
+      torch.cuda.synchronize(self.eng.device)
+    return k
+
+  def close(self):
+    try:
+      import torch
+      torch.cuda.synchronize(self.eng.device)
+      self.eng.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
 
   def finish(self):
     eng, cfg, elapsed = self.eng, self.cfg, self.elapsed
@@ -265,10 +288,16 @@ class GroupsRun(object):
     torch.cuda.synchronize(engs[0].device)
     self.elapsed = time.perf_counter() - t0
 
+  def close(self):
+    for e in getattr(self, 'engs', []):
+      try:
+        e.close()
+      except Exception:  # pylint: disable=broad-except
+        pass
+
   def finish(self):
     errors = max(int(e.error.max().item()) for e in self.engs)
-    for e in self.engs:
-      e.close()
+    self.close()
     return self.n * self.groups * self.steps / self.elapsed, errors
 
 
@@ -394,13 +423,16 @@ def assemble_line(args, res, elapsed):
   facts, variant = res['facts'], res['variant']
   image = '%dx%d' % (facts['image'][1], facts['image'][0])
   obs_bytes = 3 * facts['image'][0] * facts['image'][1]
-  counters = profiled_counters(args.workload, args.envs_per_gpu, args.aa, variant['build_id'])
+  counters, counters_state = profiled_counters(args.workload, args.envs_per_gpu, args.aa, variant['build_id'])
   second = variant['kernel']
   first = variant.get('cover_kernel', 'swb_cover_kernel')
   roofline = {
       'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
       'frac': achieved / HBM_PEAK_GBS, 'frac_of_measured_copy_peak': achieved / 6290.0,
       'traffic': counters['hbm_traffic_bytes_per_launch'] if counters else None,
+      # 'fresh': traffic / instructions below are the committed PMC passes of exactly this build; 'stale': the committed
+      # passes of this workload are of another build (not quoted); 'none': no passes committed for this workload
+      'counters': counters_state,
       'kernel': ('%s + %s' % (first, second)) if not second.startswith('none') else first + ' (paints the frame: anti_aliasing = 1)',
       'kernel_ms': kernel_s * 1e3,
       'kernel_ms_source': 'one pair of HIP events on the launch stream around the timed steps / steps',
@@ -430,20 +462,28 @@ def assemble_line(args, res, elapsed):
     # the resample kernel from exact event counts (tools/assemble_evidence.py, tools/emu_stats.py)
     valu = counters['insts_valu_per_env']
     envs_per_simd = args.envs_per_gpu / 1024.0
+    issue_frac = valu * envs_per_simd * VALU_CYCLES_PER_INST / 2.4e9 / kernel_s
     roofline['instructions'] = {
         'insts_valu_per_env': valu, 'insts_salu_per_env': counters['insts_salu_per_env'],
         'insts_valu_per_env_by_kernel': counters['insts_valu_per_env_by_kernel'],
         'valu_cycles_per_inst': VALU_CYCLES_PER_INST,
         'valu_issue_ms_per_step': valu * envs_per_simd * VALU_CYCLES_PER_INST / 2.4e9 * 1e3,
-        'valu_issue_frac_of_step': valu * envs_per_simd * VALU_CYCLES_PER_INST / 2.4e9 / kernel_s,
+        'valu_issue_frac_of_step': issue_frac,
+        'valu_busy_by_kernel': counters.get('valu_busy_by_kernel'),
         'resample_valu_model_min_per_env': counters.get('resample_valu_model_min_per_env'),
         'resample_valu_measured_over_model': (counters['insts_valu_per_env_by_kernel'].get('resample', 0) /
                                                counters['resample_valu_model_min_per_env'])
         if counters.get('resample_valu_model_min_per_env') else None,
         'source': counters['source'],
     }
+    # `bound` above is the roofline SURVEY 8d defines for this path (HBM: raster / indexing, no MFMA); what the counters say
+    # actually limits the step is named here, so that a reader of this block alone is not misled
+    roofline['bound_measured'] = ('valu-issue' if issue_frac >= 0.5 else 'latency (vector ALU %.0f %% busy)' % (100 * issue_frac))
+    roofline['bound_measured_source'] = ('vector instructions per environment x %.2f cycles on 1024 SIMDs at 2.4 GHz = %.0f %% of the '
+                                         'step (PMC passes of this build)' % (VALU_CYCLES_PER_INST, 100 * issue_frac))
   else:
-    roofline['instructions'] = None       # no committed PMC pass for this build / workload (see profiles/)
+    roofline['instructions'] = None       # no committed PMC pass for this build / workload (see `counters`)
+    roofline['bound_measured'] = None
   out = {
       'metric': 'env-steps/sec (incl. %s RGB render) at %d envs' % (image, args.envs_per_gpu),
       'value': value,
@@ -483,6 +523,9 @@ def main():
   ap.add_argument('--aa', type=int, default=5)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extra', action='store_true')
+  ap.add_argument('--ramp-ms', type=float, default=300.0,
+                  help='milliseconds of device load (a twin engine of the same workload) in front of the --warmup steps, on every '
+                       'rank at every N; 0: none')
   ap.add_argument('--no-verify', action='store_true', help='skip the oracle check of 64 sampled environments after the timed region')
   ap.add_argument('--gather-obs', action='store_true',
                   help='also all-gather the observation shards over RCCL every step (BASELINE configs[3])')
@@ -526,22 +569,41 @@ def main():
     setup_errors[:] = [(r, e) for r, e in enumerate(status) if e is not None]
     return not setup_errors
 
-  # The `extra` workloads of the default N = 1 line run BEFORE the headline's warm-up and timed steps, not after them, and every
-  # engine of the line is built before the first of them runs, so that the device goes from one timed loop to the next without
-  # idling in between.  A device that comes out of idle raises its clocks over tens of milliseconds of load
-  # (profiles/r04_launch_convergence.json: a compute-bound control kernel drifts 7 % over its first 64 launches) and drops them
-  # again within milliseconds of idling; the driver's 5 + 20 steps are 5 ms -- timed first, the headline is timed on the ramp
-  # and everything after it at speed.  The timed region itself is unchanged: exactly --warmup untimed steps, then exactly
-  # --steps timed ones.
+  # Clock ramp -- the SAME on every path (N = 1 and every rank of N > 1).  A device that comes out of idle raises its clocks
+  # over tens of milliseconds of load (profiles/r05_launch_convergence.json: a compute-bound control kernel drifts 7 % over its
+  # first 64 launches) and drops them again within milliseconds of idling; the driver's 5 + 20 steps are 5 ms of load.  So
+  # before the timed engine's --warmup steps a TWIN engine of the same workload (a) times the same W + K steps cold -- the
+  # line's `cold` block: what a fresh process gets -- and (b) keeps the device busy for --ramp-ms milliseconds.  The timed
+  # engine itself sees exactly --warmup untimed steps, then exactly --steps timed ones; `warmup_effective` says what ran in
+  # front of them.  (Round 5 ran the `extra` workloads in front of the headline instead, on the N = 1 path only: the advisor's
+  # point that an N > 1 line would then have been compared with a differently warmed N = 1 line.)  The `extra` workloads now
+  # run AFTER the headline, every engine built first, the first of them behind a ramp of its own.
+  ramp_info = {}
+
+  def clock_ramp():
+    if args.ramp_ms <= 0:
+      return
+    twin = TimedRun(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device, seed=rank + 1000).build()
+    try:
+      twin.go()
+      ramp_info['cold_ms_per_step'] = twin.event_ms / max(args.steps, 1)
+      ramp_info['cold_wall_ms_per_step'] = twin.elapsed / max(args.steps, 1) * 1e3
+      ramp_info['clock_ramp_steps'] = twin.ramp(args.ramp_ms)
+    finally:
+      twin.close()
+
   extra = {}
   extra_runs = []
 
   def build_extras():
     short = max(args.steps // 4, 10)
     for label, (nm, n, aa) in {
+        # anti_aliasing = 5 (reference-faithful) AND 1 (pure raster) for each configuration
         'cluster_s5_aa1': ('cluster_s5', args.envs_per_gpu, 1),
         'goal_s5_1024_aa5': ('goal_s5', 1024, 5),
+        'goal_s5_1024_aa1': ('goal_s5', 1024, 1),
         'embodied_s12_128_aa5': ('embodied_s12', args.envs_per_gpu, 5),
+        'embodied_s12_128_aa1': ('embodied_s12', args.envs_per_gpu, 1),
         # BASELINE configs[3]'s per-GPU share is 8192; this is the same scene with 8x the batch in ONE launch
         # (the launch's fixed fill/drain cost amortised)
         'cluster_s5_65536_aa5': ('cluster_s5', 65536, 5),
@@ -554,13 +616,23 @@ def main():
   extra_error = []
 
   def run_extras():
-    # (a failure here must not cost the line its headline: it is recorded and the extras are dropped)
+    # (a failure here must not cost the line its headline -- which has been timed by now: it is recorded, every engine built so
+    # far is closed and the extras are dropped)
     try:
       build_extras()
+      if args.ramp_ms > 0:
+        extra_runs[0][1].ramp(args.ramp_ms)
       for _, run in extra_runs:
         run.go()
     except Exception as e:  # pylint: disable=broad-except
       extra_error.append(repr(e))
+      try:
+        import torch as _t
+        _t.cuda.synchronize()
+      except Exception:  # pylint: disable=broad-except
+        pass
+      for _, run in extra_runs:
+        run.close()
       del extra_runs[:]
 
   def finish_extras():
@@ -570,6 +642,9 @@ def main():
         extra[label] = {'env_steps_per_s': rate, 'env_errors': errs}
         continue
       r = run.finish()
+      if r.get('error'):
+        extra[label] = {'error': r['error']}
+        continue
       n, short = run.n_envs, run.steps
       ks = r['kernel_ms'] / 1e3 / max(r['launches'], 1)
       extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel': r['variant']['kernel'], 'kernel_ms': ks * 1e3,
@@ -588,7 +663,7 @@ def main():
     res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
                   barrier=barrier, seed=rank, gate=gate_once if dist is not None else None,
                   verify=64 if (rank == 0 and not args.no_verify) else 0,
-                  before=run_extras if (args.gpus == 1 and dist is None and not args.no_extra) else None)
+                  before=clock_ramp)
   except Exception as e:  # pylint: disable=broad-except
     if dist is None:
       raise
@@ -652,6 +727,21 @@ def main():
     out['per_rank'] = per_rank
   if gather is not None:
     out['obs_allgather'] = gather
+  out['warmup_effective'] = {
+      'timed_engine_warmup_steps': args.warmup,
+      'clock_ramp_ms': args.ramp_ms if ramp_info else 0.0,
+      'clock_ramp_steps': ramp_info.get('clock_ramp_steps', 0),
+      'how': ('a twin engine of the same workload timed W + K steps cold, then kept the device busy for clock_ramp_ms, before the '
+              "timed engine's own W warm-up steps; identical on every rank at every N") if ramp_info else 'none (--ramp-ms 0)',
+  }
+  if ramp_info:
+    cold_s = ramp_info['cold_ms_per_step'] / 1e3
+    out['cold'] = {'value': args.envs_per_gpu * args.gpus / cold_s if cold_s > 0 else None, 'unit': 'env-steps/s',
+                   'ms_per_step': ramp_info['cold_ms_per_step'], 'wall_ms_per_step': ramp_info['cold_wall_ms_per_step'],
+                   'what': 'the same W warm-up + K timed steps on the twin engine, first thing in the process (device out of '
+                           'idle); rank 0, HIP events'}
+  if args.gpus == 1 and dist is None and not args.no_extra:
+    run_extras()
   if extra_error:
     out['extra_error'] = extra_error[0]
   if extra_runs:
@@ -660,7 +750,7 @@ def main():
     except Exception as e:  # pylint: disable=broad-except
       out['extra_error'] = repr(e)
     out['extra'] = extra
-    out['order'] = 'the extra workloads ran before the warm-up and timed steps of this line (device at its working clocks)'
+    out['order'] = 'the extra workloads ran after the timed steps of this line, behind a clock ramp of their own'
   if args.gpus == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(args.workload, args.aa)
   print(json.dumps(out))

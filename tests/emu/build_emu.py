@@ -80,6 +80,7 @@ def _instrument(text):
   after('  rs.cnt = 0; rs.s0 = rs.s1 = rs.s2 = 0u;', hook('p2_batches'))
   after('        for (int e = 0; e < ne; ++e) {', hook('p2_edge_iterations'))
   after('          for (int j = 0; j < bound; j += G) {', hook('p2_edge_iterations'), count=2)      # (the loop exists unswitched: two copies)
+  after('            for (int j = 0; j < pk_iters; ++j) {', hook('p2_edge_iterations'), count=2)   # ("active edges" form)
   after('    const int total = __builtin_amdgcn_readlane(incl, SWB_WAVE - 1);', hook('run_units', 'total'))
   anchor = '        auto take = [&]() __attribute__((always_inline)) {'
   assert text.count(anchor) == 1, anchor

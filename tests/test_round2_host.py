@@ -67,7 +67,9 @@ def test_bench_bookkeeping():
   assert bench.algorithmic_bytes(cfg) == 12461
   cfg, _, _ = workloads.build('embodied_s12', 4, 1)
   assert bench.algorithmic_bytes(cfg) == 49513
-  assert bench.profiled_counters('cluster_s5', 8192, 5, 'not-a-build-id') is None   # stale figures are never reported
+  # stale figures are never reported -- and the caller is told that they ARE stale (not merely absent)
+  assert bench.profiled_counters('cluster_s5', 8192, 5, 'not-a-build-id') == (None, 'stale')
+  assert bench.profiled_counters('no_such_workload', 8192, 5, 'not-a-build-id') == (None, 'none')
   assert bench.usable_cores() >= 1
 
 
@@ -102,10 +104,13 @@ def test_bench_line_carries_the_committed_counters_of_this_build():
     assert [k['name'] for k in r['kernels']] == ([cover] if one_kernel else [cover, kernel])
     assert abs(sum(k['ms'] for k in r['kernels']) - r['kernel_ms']) < 1e-9
     assert abs(r['achieved'] - a_bytes * 8192 / (r['kernel_ms'] * 1e-3) / 1e9) < 1e-6
-    counters = bench.profiled_counters(workload, 8192, aa, build_id)
-    if counters is None:        # the kernel sources changed after the last PMC passes: stale figures are not reported
-      assert r['traffic'] is None and r['instructions'] is None
+    counters, state = bench.profiled_counters(workload, 8192, aa, build_id)
+    assert r['counters'] == state
+    if counters is None:        # the kernel sources changed after the last PMC passes: stale figures are not reported,
+      assert state == 'stale'   # and the line says so
+      assert r['traffic'] is None and r['instructions'] is None and r['bound_measured'] is None
       continue
+    assert state == 'fresh' and r['bound_measured'] is not None
     assert counters['kernel'] == r['kernel']
     assert r['traffic'] == counters['hbm_traffic_bytes_per_launch'] > a_bytes * 8192
     ins = r['instructions']
@@ -116,4 +121,4 @@ def test_bench_line_carries_the_committed_counters_of_this_build():
       assert 1.0 <= ins['resample_valu_measured_over_model'] < 2.0
     res['variant'] = dict(res['variant'], build_id='0000000000000000')
     stale = bench.assemble_line(args, res, 0.0046)['roofline']
-    assert stale['traffic'] is None and stale['instructions'] is None
+    assert stale['traffic'] is None and stale['instructions'] is None and stale['counters'] == 'stale'

@@ -55,12 +55,12 @@ def main():
       if role:
         by[role] = dict(c, kernel=kernel)
     lines = open(os.path.join(d, 'summary.md')).read().rstrip().split('\n') if os.path.exists(os.path.join(d, 'summary.md')) else []
+    kms = {('cover' if 'cover' in k['name'] else 'resample'): k['ms'] for k in bench['roofline']['kernels']}
     if by:
       lines += ['', '## Counters per kernel (rocprofv3 --pmc, one process per counter set, tools/pmc_sets.sh; averages per dispatch, '
                 'per environment where divided)', '',
                 '| kernel | waves | VALU / env | SALU / env | LDS / env | SMEM / env | wave quad-cycles / wave | vector ALU busy (SQ_ACTIVE_INST_VALU x 4 cycles '
                 '/ 1024 SIMDs / 2.4 GHz / kernel time) | WRITE_SIZE MB | 2 x FETCH_SIZE MB |', '|---|---|---|---|---|---|---|---|---|---|']
-      kms = {('cover' if 'cover' in k['name'] else 'resample'): k['ms'] for k in bench['roofline']['kernels']}
       for role in ('cover', 'resample'):
         c = by.get(role)
         if not c:
@@ -83,6 +83,9 @@ def main():
         'insts_valu_per_env_by_kernel': {r: c.get('SQ_INSTS_VALU', 0) / envs for r, c in by.items()},
         'insts_salu_per_env_by_kernel': {r: c.get('SQ_INSTS_SALU', 0) / envs for r, c in by.items()},
         'wave_cycles_per_wave_by_kernel': {r: c.get('SQ_WAVE_CYCLES', 0) / max(c.get('SQ_WAVES', envs), 1) for r, c in by.items()},
+        # vector ALU busy: SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / 1024 SIMDs / 2.4 GHz / the kernel's own duration
+        'valu_busy_by_kernel': {r: c['SQ_ACTIVE_INST_VALU'] * 4.0 / 1024.0 / 2.4e9 / max(kms.get(r, 0.0) * 1e-3, 1e-12)
+                                for r, c in by.items() if 'SQ_ACTIVE_INST_VALU' in c} if by else None,
         'hbm_traffic_bytes_per_launch': int(traffic) if have_traffic else None,
         'hbm_traffic_by_kernel': {r: int((c.get('WRITE_SIZE', 0) + 2.0 * c.get('FETCH_SIZE', 0)) * 1024) for r, c in by.items()} if have_traffic else None,
         'fetch_correction': 2.0, 'algorithmic_bytes_per_launch': a_bytes,
