@@ -294,6 +294,18 @@ int swb_render(swb_handle h, uint8_t* obs_dev, void* stream);
  * task (tasks.py:153-158, :239-245, :289-296) in the cover kernel's state phase; no state change, no time step, no frame. */
 int swb_evaluate(swb_handle h, uint8_t* success_dev, void* stream);
 
+/* Memory of the hand-off lists (what the cover kernel hands the resample / fill kernel: swb_variant_info::run_list_bytes).
+ * A handle starts with a list of max(4, max_sprites + 1) units of 8 bytes per canvas row for every environment and group of 64
+ * output columns -- enough for ANY scene of convex sprites, about ten times what the usual scene needs (133 KB per environment
+ * for 12 sprites at 128x128 with anti_aliasing 5).  This call, made once the handle has rendered a few typical steps, cuts every
+ * list's own part down to 1.25 x the longest list of the last launch and adds a shared arena (a quarter of the parts together)
+ * from which a list that outgrows its part continues; a scene that finds the arena exhausted too is flagged
+ * SWB_ENV_ERR_SPAN_OVERFLOW (never silent).  Results do not change.  Blocking (synchronises `stream`, reallocates); no-op when
+ * called again.  swb_set_pool / swb_sample_pool restore the full reservation (the new pool may hold denser scenes).
+ * run_cap_out (may be NULL): the units of a list's own part afterwards.  The Python engine calls it after its third
+ * rendering step. */
+int swb_trim_run_lists(swb_handle h, int32_t* run_cap_out, void* stream);
+
 /* SpriteFactors observation (renderers/handcrafted.py:29-82): factors_dev f64[N,S,10] in
  * sprite.FACTOR_NAMES order (x, y, shape, angle, scale, c0, c1, c2, x_vel, y_vel), `shape` as its
  * constants.ShapeType value (1-based); rows >= n_sprites[env] are zero. */
@@ -362,10 +374,14 @@ typedef struct swb_variant_info {
   int32_t resample_waves_per_simd; /* ... the resample / fill kernel */
   int32_t n_bands;            /* bands of output rows: waves of the second kernel per (environment, column group) */
   int32_t n_column_groups;    /* groups of 64 output columns */
-  int32_t run_cap;            /* capacity of a run list (8-byte units per environment and column group): max(4, max_sprites + 1)
-                               * per canvas row -- any scene of convex sprites fits; a list that overflows flags its environment */
+  int32_t run_cap;            /* the fixed part of a run list (8-byte units per environment and column group): 1.5 canvas heights,
+                               * 2 from nine sprites on; a list that outgrows it continues in segments of the shared arena */
   int32_t paint_in_cover;     /* 1: anti_aliasing = 1 and an image of up to 64 columns -- the cover kernel writes the frame
                                * itself and no second kernel is launched */
+  int32_t arena_units;        /* units of the arena the run lists of all environments share for their overflow (0 until the first
+                               * launch allocates it); a scene that finds it exhausted flags its environment */
+  int32_t reserved_;
+  int64_t run_list_bytes;     /* device memory of the hand-off lists: fixed parts + arena (0 until the first launch) */
 } swb_variant_info;
 int swb_variant(swb_handle h, swb_variant_info* out);
 const char* swb_build_id(void);

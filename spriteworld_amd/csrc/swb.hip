@@ -99,7 +99,11 @@ struct swb_engine {
   int launch_phase = 0;              // launch count % 3 (swb_params::cphase)
   int launch_parity = 0;
   // hand-off cover -> resample
-  uint32_t *d_runs = nullptr, *d_rhdr = nullptr;
+  uint32_t *d_runs = nullptr, *d_rhdr = nullptr, *d_arena_head = nullptr;
+  int arena_override = -1;           // SWB_ARENA_UNITS (tests): units of the shared arena; -1: sized from the batch
+  int run_cap_worst = 0;             // (max(4, S + 1) canvas heights + 1: what a list reserves until swb_trim_run_lists)
+  bool lists_trimmed = false;        // the lists have been cut down to what the launches so far needed
+  bool lists_valid = false;          // the last launch wrote them (it rendered through the second kernel)
   int32_t *d_band_y0 = nullptr, *d_band_first = nullptr, *d_band_lo = nullptr, *d_cg_lo = nullptr, *d_cg_hi = nullptr;
   uint32_t* d_v_break = nullptr;
   // live sprite overrides (swb_set_sprite_attr), allocated at the first call
@@ -188,8 +192,10 @@ int ensure_overflow_slots(swb_engine* h, kernel_fn fn, kernel_fn fn_alt, size_t 
 
 // Bands of output rows, the rows at which a run must end, and the canvas columns each group of 64 output columns
 // can see -- from the resampling tables (anti_aliasing > 1) or the identity (anti_aliasing = 1).
-int ensure_handoff_tables(swb_engine* h) {
-  if (!h->tables_dirty) return 0;
+// need_lists = false: a handle whose cover kernel paints the frame itself (anti_aliasing = 1, an image of up to 64 columns)
+// never hands anything to a second kernel and reserves no lists.
+int ensure_handoff_tables(swb_engine* h, bool need_lists = true) {
+  if (!h->tables_dirty && (h->d_runs || !need_lists)) return 0;
   swb_params& p = h->p;
   int nb = h->nbands;
   p.ncg = (p.Wo + 63) / 64;
@@ -241,14 +247,53 @@ int ensure_handoff_tables(swb_engine* h) {
     return SWB_ERR_HIP;
   p.band_lo = h->d_band_lo;
   p.band_y0 = h->d_band_y0; p.band_first = h->d_band_first; p.v_break = h->d_v_break; p.cg_lo = h->d_cg_lo; p.cg_hi = h->d_cg_hi;
-  // run lists: run_cap units of 8 bytes per (environment, column group) + 4 units of slack behind each list (the
-  // resample kernel reads a run's first 16 bytes in one go)
-  if (!h->d_runs) {
-    if (upload(&h->d_runs, (const uint32_t*)nullptr, ((size_t)p.N * p.ncg * p.run_cap + 4) * 2)) return SWB_ERR_HIP;
+  // run lists: run_cap units of 8 bytes per (environment, column group), then the shared arena their overflow segments
+  // come from, then 4 units of slack (the resample kernel reads a run's first 16 bytes in one go)
+  if (!h->d_runs && need_lists) {
+    const size_t fixed = (size_t)p.N * p.ncg * p.run_cap;
+    // arena: a quarter of the fixed parts once they have been trimmed (before that they hold any scene of convex sprites by
+    // themselves), and at least eight worst-case lists
+    size_t arena = std::max(h->lists_trimmed ? fixed / 4 : (size_t)0, (size_t)8 * h->run_cap_worst);
+    if (h->arena_override >= 0) arena = (size_t)h->arena_override;
+    const size_t units = fixed + arena + 4;
+    if (units * 8 >= ((size_t)1 << 32))                                  // (list positions are 32-bit byte offsets)
+      return fail(SWB_ERR_INVALID, "run lists of %zu MB (%d environments x %d column groups x %d units + an arena of %zu units) exceed "
+                  "the 4 GB a list position can address: step fewer environments per engine", units * 8 >> 20, p.N, p.ncg, p.run_cap, arena);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && units * 8 + (size_t)p.N * SWB_RHDR_DWORDS * 4 > free_b)
+      return fail(SWB_ERR_HIP, "run lists need %zu MB of device memory (%d environments x %d column groups x %d units of 8 bytes + an "
+                  "arena of %zu units), %zu MB are free", units * 8 >> 20, p.N, p.ncg, p.run_cap, arena, free_b >> 20);
+    if (upload(&h->d_runs, (const uint32_t*)nullptr, units * 2)) return SWB_ERR_HIP;
     if (upload(&h->d_rhdr, (const uint32_t*)nullptr, (size_t)p.N * SWB_RHDR_DWORDS)) return SWB_ERR_HIP;
+    if (upload(&h->d_arena_head, (const uint32_t*)nullptr, 2)) return SWB_ERR_HIP;
     p.runs = h->d_runs; p.rhdr = h->d_rhdr;
+    p.arena_head = h->d_arena_head;
+    p.arena_base = (int64_t)fixed;
+    p.arena_units = (int32_t)std::min(arena, (size_t)0x7fffffff);
+    p.arena_chunk = std::max(16, p.run_cap / 2);
   }
   h->tables_dirty = false;
+  return 0;
+}
+
+// Frees the hand-off lists; the next launch allocates them again with the capacity h->p.run_cap holds by then.
+int drop_run_lists(swb_engine* h) {
+  if (!h->d_runs) return 0;
+  HIP_TRY(hipDeviceSynchronize());
+  (void)hipFree(h->d_runs); (void)hipFree(h->d_rhdr); (void)hipFree(h->d_arena_head);
+  h->d_runs = nullptr; h->d_rhdr = nullptr; h->d_arena_head = nullptr;
+  h->p.runs = nullptr; h->p.rhdr = nullptr; h->p.arena_head = nullptr;
+  h->lists_valid = false;
+  h->tables_dirty = true;
+  return 0;
+}
+
+// A new pool may hold denser scenes than the one the lists were trimmed to: back to the full reservation.
+int restore_run_list_reservation(swb_engine* h) {
+  if (!h->lists_trimmed) return 0;
+  if (int rc = drop_run_lists(h)) return rc;
+  h->lists_trimmed = false;
+  if (!getenv("SWB_RUN_CAP")) h->p.run_cap = h->run_cap_worst;
   return 0;
 }
 
@@ -275,7 +320,8 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
     return fail(SWB_ERR_STATE, "swb_upload_resample (both axes) is required when anti_aliasing > 1");
   const variant* v = pick_variant(h->p.Wc);
   if (!v) return fail(SWB_ERR_INVALID, "canvas %dx%d not supported", h->p.Wc, h->p.Hc);
-  if (int rc = ensure_handoff_tables(h)) return rc;
+  const bool paints_itself = h->p.AA == 1 && (h->p.Wo + 63) / 64 == 1 && !h->no_paint_in_cover && v->fn_paint;
+  if (int rc = ensure_handoff_tables(h, !paints_itself)) return rc;
   int vs = 0;
   const kernel_fn fn2 = pick_resample(h->p.AA, h->vslots, &vs);
   swb_params p = h->p;
@@ -356,9 +402,20 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   if (h->timing && !p.paint_in_cover) HIP_TRY(hipEventRecord(ev.e1, stream));
   if (p.obs && !p.paint_in_cover) launch_resample(0, c.n_envs, stream);
   HIP_TRY(hipGetLastError());
-  if (!p.obs && p.cost_cnt)       // no second kernel to clear the next launch's bucket counters (kind 0; the cover kernel keeps kind 1)
+  if (!p.obs && p.cost_cnt && render_only != 2)   // no second kernel to clear the next launch's bucket counters (kind 0; the cover kernel keeps kind 1)
     HIP_TRY(hipMemsetAsync(h->d_cost_cnt + (size_t)(p.parity ^ 1) * SWB_COST_SET, 0, SWB_COST_SET * sizeof(uint32_t), stream));
+  if (render_only == 2) {
+    // swb_evaluate files nothing and lists nothing: the dispatch state (parity, phase, what the previous launch filed) stays as
+    // the last step left it -- an evaluation between two steps does not cost the next one its cost order (round-5 advice)
+    if (h->timing) {
+      HIP_TRY(hipEventRecord(ev.e1, stream));
+      HIP_TRY(hipEventRecord(ev.e2, stream));
+      h->event_pool.push_back(ev);
+    }
+    return 0;
+  }
   h->cover_lists_filed = p.obs && p.ccost_list;
+  h->lists_valid = p.obs && !p.paint_in_cover;
   h->launch_phase = (h->launch_phase + 1) % 3;
   h->launch_parity ^= 1;
   if (h->timing) {
@@ -431,9 +488,9 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
     if (const char* x = getenv("SWB_BANDS")) nb = std::max(1, std::min(atoi(x), (int)SWB_MAX_BANDS));
     h->nbands = std::min(nb, p.Ho);
   }
-  // run lists: 8-byte units per (environment, column group); a canvas row costs 1 unit (one span), 2 (two or three)
-  // or more, and rows that repeat the row above cost nothing
-  // cost buckets: 32 of them over run lists of up to ~Hc units (longer lists share the last one)
+  // cost buckets of the second kernel's tasks: 32 of them over the cost of a run list (3 per run + 2 per 8-byte unit: a canvas row
+  // costs 1 unit (one span), 2 (two or three) or more, and rows that repeat the row above nothing); the range they span is
+  // fitted by every launch (cost_housekeeping), to begin with it is [0, 8 * canvas height)
   p.cost_range0 = std::max(8 * p.Hc, SWB_KEY_BUCKETS_FITTED);      // (a run and its units cost 5 .. 9; a launch later the range is a measured one)
   if (!getenv("SWB_NO_COST_ORDER") && p.N < (1 << 24)) {
     p.cost_cap = ((p.Wo + 63) / 64) * ((p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS);
@@ -474,14 +531,17 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
       while ((1 << p.deal_shift) < per_xcd) ++p.deal_shift;
     if (const char* x = getenv("SWB_DEAL_SHIFT")) p.deal_shift = std::max(0, atoi(x));      // tests: short rounds on small batches
   }
-  // Capacity of a run list in 8-byte units.  A canvas row of s >= 2 visible spans costs 1 + s / 2 units and S convex sprites
-  // leave at most 2 S - 1 spans in a row: (S + 1) units per row hold any scene of convex sprites even if no two rows fold
-  // into a run (the usual scene needs a seventh of that).  Until round 5 the capacity was 4 rows' worth whatever S: ten
-  // sprites on a 60-row canvas overflowed it (seed 2681 of tools/fuzz_sweep.py: the environment flagged, its frame short of a
-  // batch of rows).  Non-convex sprites can exceed any such bound in principle; a list that still overflows flags its
-  // environment (SWB_ENV_ERR_SPAN_OVERFLOW).
-  p.run_cap = std::max(4, p.S + 1) * p.Hc + 1;
+  // Run lists, in 8-byte units.  A canvas row of s >= 2 visible spans costs 1 + s / 2 units and S convex sprites leave at most
+  // 2 S - 1 spans in a row: (S + 1) units per row hold any scene of convex sprites even if no two rows fold into a run.  That is
+  // what every list reserves to BEGIN with (round 5: ten sprites on a 60-row canvas needed 4.5 units per row) -- 133 KB per
+  // environment on 12 sprites at 128x128, a tenth of it used.  swb_trim_run_lists() then cuts the lists' own (fixed) parts down to
+  // 1.25 x the longest list the launches so far wrote and adds a shared ARENA from which a list that outgrows its part continues
+  // by atomic bump (swb_params::run_cap); only a scene that finds the arena exhausted too is flagged (SWB_ENV_ERR_SPAN_OVERFLOW,
+  // its frame short of a batch of rows) -- never silently.  A new pool (swb_set_pool / swb_sample_pool) restores the reservation.
+  h->run_cap_worst = std::max(4, p.S + 1) * p.Hc + 1;
+  p.run_cap = h->run_cap_worst;
   if (const char* x = getenv("SWB_RUN_CAP")) p.run_cap = std::max(8, atoi(x));      // tests
+  if (const char* x = getenv("SWB_ARENA_UNITS")) h->arena_override = std::max(0, atoi(x));   // tests (0: no arena)
   const size_t NS = (size_t)p.N * p.S;
   int rc = 0;
   rc |= upload(&h->d_x, (const double*)nullptr, NS);
@@ -516,7 +576,7 @@ int swb_destroy(swb_handle h) {
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_p_attr, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
                   h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler,
                   h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label,
-                  h->d_cost_cnt, h->d_cost_list, h->d_ccost_list, h->d_runs, h->d_rhdr, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
+                  h->d_cost_cnt, h->d_cost_list, h->d_ccost_list, h->d_runs, h->d_rhdr, h->d_arena_head, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;
@@ -698,6 +758,7 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
   HIP_TRY(hipMemset(h->d_episode, 0, sizeof(int32_t) * N));
   HIP_TRY(hipMemset(h->d_step_count, 0, sizeof(int32_t) * N));
   h->have_pool = true;
+  if (int rc2 = restore_run_list_reservation(h)) return rc2;
   return SWB_OK;
 }
 
@@ -809,6 +870,7 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
   HIP_TRY(hipMemsetAsync(h->d_episode, 0, sizeof(int32_t) * N, st));
   HIP_TRY(hipMemsetAsync(h->d_step_count, 0, sizeof(int32_t) * N, st));
   h->have_pool = true;
+  if (int rc2 = restore_run_list_reservation(h)) return rc2;
   h->pool_sampled = true;
   h->pool_uniform = true;
   for (int i = 0; i < N; ++i)
@@ -892,6 +954,32 @@ int swb_evaluate(swb_handle h, uint8_t* success_dev, void* stream) {
   memset(&out, 0, sizeof(out));
   out.success = success_dev;
   return launch(h, nullptr, &out, 2, (hipStream_t)stream);
+}
+
+int swb_trim_run_lists(swb_handle h, int32_t* run_cap_out, void* stream) {
+  if (!h) return fail(SWB_ERR_INVALID, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if (run_cap_out) *run_cap_out = h->p.run_cap;
+  if (h->lists_trimmed || getenv("SWB_RUN_CAP") || getenv("SWB_NO_TRIM")) return SWB_OK;   // (done already / a test pinned the capacity)
+  if (!h->d_runs && h->p.AA == 1 && (h->p.Wo + 63) / 64 == 1) return SWB_OK;      // (the cover kernel paints the frame: no lists at all)
+  if (!h->d_runs || !h->lists_valid) return fail(SWB_ERR_STATE, "swb_trim_run_lists: the last launch listed no runs (step or render first)");
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  // the longest list of the last launch: its end is in the header (no list has left its fixed part: it holds any scene)
+  const swb_params& p = h->p;
+  std::vector<uint32_t> hdr((size_t)p.N * SWB_RHDR_DWORDS);
+  HIP_TRY(hipMemcpy(hdr.data(), h->d_rhdr, hdr.size() * 4, hipMemcpyDeviceToHost));
+  uint32_t longest = 0;
+  for (int n = 0; n < p.N; ++n)
+    for (int g = 0; g < p.ncg; ++g) longest = std::max(longest, hdr[(size_t)n * SWB_RHDR_DWORDS + SWB_RHDR_GROUPS + g * SWB_RHDR_GSTRIDE]);
+  if (longest >= (uint32_t)p.run_cap) return SWB_OK;                 // (cannot be: keep what there is)
+  const int want = std::max(p.Hc / 2, (int)(longest + longest / 4 + 16)) + 1;
+  if (want >= p.run_cap) return SWB_OK;                              // nothing to gain
+  if (int rc = drop_run_lists(h)) return rc;
+  h->p.run_cap = want;
+  h->lists_trimmed = true;
+  if (int rc = ensure_handoff_tables(h)) return rc;
+  if (run_cap_out) *run_cap_out = h->p.run_cap;
+  return SWB_OK;
 }
 
 int swb_factors(swb_handle h, double* factors_dev, void* stream) {
@@ -1174,6 +1262,9 @@ int swb_variant(swb_handle h, swb_variant_info* out) {
   out->n_column_groups = (h->p.Wo + 63) / 64;
   out->run_cap = h->p.run_cap;
   out->paint_in_cover = (h->p.AA == 1 && (h->p.Wo + 63) / 64 == 1 && !h->no_paint_in_cover) ? 1 : 0;
+  out->arena_units = h->d_runs ? h->p.arena_units : 0;
+  out->reserved_ = 0;
+  out->run_list_bytes = h->d_runs ? ((int64_t)h->p.arena_base + h->p.arena_units + 4) * 8 : 0;
   return SWB_OK;
 }
 

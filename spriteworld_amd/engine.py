@@ -55,6 +55,9 @@ class Engine(object):
       self.error = torch.zeros(self.N, dtype=torch.uint8, device=self.device)
     self._outs = self._make_outs(render=True)
     self._outs_norender = self._make_outs(render=False)
+    self._rendered = 0        # rendering launches so far (the run lists are trimmed after TRIM_AFTER of them)
+
+  TRIM_AFTER = 3
 
   def _make_outs(self, render):
     o = _abi.SwbOutputs()
@@ -85,6 +88,7 @@ class Engine(object):
     self.pool = pool
     cpool = pool.as_struct()
     _lib.check(self.lib.swb_set_pool(self._h, C.byref(cpool)))
+    self._rendered = 0        # (a new pool restores the lists' full reservation: trimmed again after TRIM_AFTER launches)
 
   def sample_pool(self, spec, n_entries, pool_base, pool_len, seed, first_entry=0):
     """Draws `n_entries` episodes on the device from an _abi.SwbSampler (swb_sample_pool)."""
@@ -96,6 +100,7 @@ class Engine(object):
                                         self._stream()))
     self.pool = None
     self._pool_entries = int(n_entries)
+    self._rendered = 0
 
   def resample_pool(self, seed, first_entry=0):
     """Fresh episodes in every pool entry no environment is playing; nothing is reset (swb_resample_pool)."""
@@ -131,6 +136,21 @@ class Engine(object):
     outs = self._outs if render else self._outs_norender
     _lib.check(self.lib.swb_step(self._h, C.c_void_p(actions.data_ptr()), C.byref(outs),
                                  self._stream()))
+    if render:
+      self._rendered += 1
+      if self._rendered == self.TRIM_AFTER:
+        self.trim()
+
+  def trim(self):
+    """Cuts the hand-off lists between the two kernels of a step from their start-up reservation (any scene of convex sprites:
+    133 KB per environment on 12 sprites at 128x128) down to 1.25 x what the launches so far needed, plus a shared arena for the
+    lists that outgrow that (swb_trim_run_lists; blocking, once -- `step()` calls it after its third rendering launch, so it
+    falls into any warm-up).  Returns the units of 8 bytes a list owns afterwards.  Results never change."""
+    if not hasattr(self.lib, 'swb_trim_run_lists'):      # (an A/B build of an older revision)
+      return None
+    cap = C.c_int32(0)
+    _lib.check(self.lib.swb_trim_run_lists(self._h, C.byref(cap), self._stream()))
+    return cap.value
 
   def render(self):
     _lib.check(self.lib.swb_render(self._h, C.c_void_p(self.obs.data_ptr()), self._stream()))

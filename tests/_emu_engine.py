@@ -43,6 +43,8 @@ def lib():
     if hasattr(l, 'swb_evaluate') or not os.environ.get('SWB_EMU_CSRC'):      # (an older copy of the sources may lack it)
       l.swb_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     l.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    if hasattr(l, 'swb_trim_run_lists') or not os.environ.get('SWB_EMU_CSRC'):
+      l.swb_trim_run_lists.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
     l.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
     l.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     l.swb_set_sprite_attr.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -113,6 +115,7 @@ class EmuEngine(object):
     self.pool = pool
     cpool = pool.as_struct()
     check(self.lib.swb_set_pool(self._h, C.byref(cpool)))
+    self._rendered = 0
 
   def sample_pool(self, spec, n_entries, pool_base, pool_len, seed, first_entry=0):
     base = np.ascontiguousarray(pool_base, dtype=np.int32)
@@ -121,6 +124,7 @@ class EmuEngine(object):
                                    C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_uint64(int(first_entry)), None))
     self.pool = None
     self._pool_entries = int(n_entries)
+    self._rendered = 0
 
   def resample_pool(self, seed, first_entry=0):
     check(self.lib.swb_resample_pool(self._h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_uint64(int(first_entry)), None))
@@ -145,6 +149,17 @@ class EmuEngine(object):
       a = np.ascontiguousarray(actions, dtype=np.float32 if self.cfg.action_is_f32 else np.float64).reshape(self.N, 4)
     outs = self._outs(render)
     check(self.lib.swb_step(self._h, _ptr(a), C.byref(outs), None))
+    if render:                          # (as engine.Engine: the run lists are trimmed after the third rendering launch)
+      self._rendered = getattr(self, '_rendered', 0) + 1
+      if self._rendered == 3:
+        self.trim()
+
+  def trim(self):
+    if not hasattr(self.lib, 'swb_trim_run_lists'):
+      return None
+    cap = C.c_int32(0)
+    check(self.lib.swb_trim_run_lists(self._h, C.byref(cap), None))
+    return cap.value
 
   def render(self):
     check(self.lib.swb_render(self._h, _ptr(self.obs), None))

@@ -40,15 +40,23 @@ def _rewrite(text, name):
   text, n = re.subn(r'using cptr = const T __attribute__\(\(address_space\(4\)\)\)\*;', 'using cptr = const T*;   /* emu */', text)
   assert n == 1, 'constant address space alias not found'
   assert 'asm(' not in text.replace('asm("")', ''), 'an inline-assembly statement is left'
-  # bounds checks on the hand-off lists (counted by emu_violations(), see emu_runtime.cc): a run record is read at a unit
-  # below the list's capacity -- the sentinel is the last unit a list can hold
+  # bounds checks on the hand-off lists (counted by emu_violations(), see emu_runtime.cc): a run record is read at a unit of
+  # the list's own fixed part -- the sentinel / jump unit is the last one a segment can hold -- or inside the shared arena
   text = text.replace('#define SWB_WAVE 64', '#define SWB_WAVE 64\nextern "C" void emu_check(int ok);', 1)
+  ok_fn = ('\n// emu: is unit `u` (relative to the first unit of the list of (env, g)) one a run record may be read at?\n'
+           'static inline int emu_list_unit_ok(const swb_params& p, int env, int g, long long u) {\n'
+           '  if (u >= 0 && u < p.run_cap) return 1;\n'
+           '  const long long a = ((long long)env * p.ncg + g) * p.run_cap + u - p.arena_base;\n'
+           '  return a >= 0 && a < p.arena_units;\n}\n')
+  anchor = '#define SWB_MAX_CG 4 '
+  assert text.count(anchor) == 1, anchor
+  text = text.replace(anchor, ok_fn + anchor)
   anchor = 'rec = *reinterpret_cast<cptr<swb_u4>>(runs + uo);'
-  assert text.count(anchor) == 2, anchor
-  text = text.replace(anchor, anchor + ' emu_check(uo < 8u * (uint32_t)p.run_cap);')
+  assert text.count(anchor) == 3, anchor
+  text = text.replace(anchor, anchor + ' emu_check(emu_list_unit_ok(p, env, g, uo >> 3));')
   anchor = 'hd = runs[2 * u]; s0 = runs[2 * u + 1];'
   assert text.count(anchor) == 1, anchor
-  text = text.replace(anchor, 'emu_check(u < p.run_cap); ' + anchor)
+  text = text.replace(anchor, 'emu_check(emu_list_unit_ok(p, env, g, u)); ' + anchor)
   if os.environ.get('SWB_EMU_STATS'):
     text = _instrument(text)
   return text
@@ -57,7 +65,7 @@ def _rewrite(text, name):
 # SWB_EMU_STATS=1: event counters at a few anchor points of the kernel source (counted by lane 0 of each wave), read back
 # through emu_stats() -- exact dynamic figures for the cost model in DESIGN.md (tools/emu_stats.py).
 _COUNTERS = ('p3_row_runs', 'p3_rows_in_runs', 'p3_spans', 'p3_completed_rows', 'p3_clean_rows', 'p2_batches',
-             'p2_sprite_passes', 'p2_edge_iterations', 'p2_transition_steps', 'run_units')
+             'p2_sprite_passes', 'p2_edge_iterations', 'p2_transition_steps', 'run_units', 'p2_chunks', 'p2_packed_passes', 'p2_words')
 
 
 def _instrument(text):
@@ -82,6 +90,9 @@ def _instrument(text):
   after('          for (int j = 0; j < bound; j += G) {', hook('p2_edge_iterations'), count=2)      # (the loop exists unswitched: two copies)
   after('            for (int j = 0; j < pk_iters; ++j) {', hook('p2_edge_iterations'), count=2)   # ("active edges" form)
   after('    const int total = __builtin_amdgcn_readlane(incl, SWB_WAVE - 1);', hook('run_units', 'total'))
+  after('    for (int wc = w0; wc <= w1; wc += NWA) {', hook('p2_chunks'))
+  after('        if (!((wbits >> w) & 1u)) continue;         // uniform: not in this chunk\n', '       ' + hook('p2_words') + '\n')
+  after('        pk_hlines = __ballot(have && horiz && ed.y0 >= yb && ed.y0 <= yb + 63 && ed.y0 < p.Hc) != 0ull;', hook('p2_packed_passes'))
   anchor = '        auto take = [&]() __attribute__((always_inline)) {'
   assert text.count(anchor) == 1, anchor
   text = text.replace(anchor, anchor + hook('p2_transition_steps') + ' ')

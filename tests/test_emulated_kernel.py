@@ -205,6 +205,7 @@ def test_emulated_kernel_run_list_overflow_is_flagged(monkeypatch, run_cap, band
   import ctypes as C
   from spriteworld_amd import _abi
   monkeypatch.setenv('SWB_RUN_CAP', str(run_cap))
+  monkeypatch.setenv('SWB_ARENA_UNITS', '0')               # (no shared arena to continue in: the round-5 layout)
   monkeypatch.setenv('SWB_BANDS', str(bands))
   for aa, name in ((5, 'cluster_s5'), (1, 'wide_s4')):
     if aa == 1:
@@ -219,6 +220,83 @@ def test_emulated_kernel_run_list_overflow_is_flagged(monkeypatch, run_cap, band
     got = eng.outputs_host()
     assert (got['error'] & _abi.ENV_ERR_SPAN_OVERFLOW).any()
     assert eng.lib.emu_violations(1) == 0
+    eng.close()
+
+
+@pytest.mark.parametrize('run_cap,bands,arena', [(8, 1, 1 << 20), (8, 4, 1 << 20), (12, 8, 1 << 20), (40, 2, 1 << 20), (24, 1, 600)])
+def test_emulated_kernel_run_lists_continue_in_the_shared_arena(monkeypatch, run_cap, bands, arena):
+  """Round 6: a run list owns a small fixed part and continues in segments of a shared arena (jump units) when it outgrows
+  it.  With a fixed part of 8 .. 40 units EVERY list jumps, several times: frames, state and rewards stay bit-exact on both
+  second kernels (resample: anti_aliasing 5; fill: anti_aliasing 1 on a wide image), no environment is flagged, and no run
+  record is read outside the list's own part or the arena.  With an arena too small for the batch (600 units) the
+  environments that find it exhausted are FLAGGED and every other one is still exact."""
+  import ctypes as C
+  from oracle import oracle
+  from spriteworld_amd import _abi
+  monkeypatch.setenv('SWB_RUN_CAP', str(run_cap))
+  monkeypatch.setenv('SWB_ARENA_UNITS', str(arena))
+  monkeypatch.setenv('SWB_BANDS', str(bands))
+  for aa, name, n_envs in ((5, 'cluster_s5', 5), (1, 'geom_160x48', 3), (5, 'embodied_s12', 2)):
+    if aa == 1:
+      monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')
+    cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=2, seed=1, anti_aliasing=aa)
+    eng, ora = _emu(cfg, pool), oracle.Engine(cfg, pool)
+    eng.lib.emu_violations.restype = C.c_long
+    eng.lib.emu_violations(1)
+    rng = np.random.default_rng(0)
+    flagged_any = False
+    for _ in range(3):
+      a = sample(rng)
+      want = ora.step(a)
+      eng.step(a)
+      got = eng.outputs_host()
+      flagged = (got['error'] & _abi.ENV_ERR_SPAN_OVERFLOW) != 0
+      flagged_any |= bool(flagged.any())
+      if arena >= (1 << 20):
+        assert not flagged.any()
+      assert np.array_equal(got['obs'][~flagged], want['obs'][~flagged])
+      assert np.array_equal(got['step_type'], want['step_type'])
+      ok = ~np.isnan(want['reward'])
+      assert np.array_equal(got['reward'][ok].view(np.uint64), want['reward'][ok].view(np.uint64))
+    if arena < (1 << 20) and name == 'embodied_s12':
+      assert flagged_any                         # (two 12-sprite scenes at 128x128 need thousands of units: 600 are exhausted)
+    assert eng.lib.emu_violations(1) == 0
+    v = eng.variant()
+    assert v['run_cap'] == run_cap and v['arena_units'] == arena and v['run_list_bytes'] > 0
+    eng.close()
+
+
+def test_emulated_run_lists_are_trimmed_after_the_third_rendering_launch():
+  """The lists start with room for any scene of convex sprites (max(4, S + 1) units per canvas row); after the third rendering
+  launch the engine cuts them to 1.25 x the longest list written + a shared arena (swb_trim_run_lists).  Frames stay exact
+  before, at and after the cut; a scene that later grows beyond its part continues in the arena; a new pool restores the
+  reservation."""
+  from oracle import oracle
+  for name, n_envs, aa in (('embodied_s12', 3, 5), ('cluster_s5', 6, 5), ('geom_160x48', 3, 1)):
+    cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=3, seed=2, anti_aliasing=aa)
+    eng, ora = _emu(cfg, pool), oracle.Engine(cfg, pool)
+    rng = np.random.default_rng(5)
+    sizes = []
+    for t in range(7):
+      a = sample(rng)
+      want = ora.step(a)
+      eng.step(a)
+      got = eng.outputs_host()
+      assert not got['error'].any()
+      assert np.array_equal(got['obs'], want['obs']), (name, t)
+      v = eng.variant()
+      sizes.append((v['run_cap'], v['arena_units'], v['run_list_bytes']))
+    worst = max(4, cfg.max_sprites + 1) * cfg.anti_aliasing * cfg.image_w + 1
+    assert sizes[0][0] == sizes[1][0] == worst                     # the start-up reservation ...
+    assert sizes[2][0] < worst // 2 and sizes[2][2] < sizes[1][2], sizes           # ... cut at the third launch
+    fixed_before, fixed_after = sizes[1][2] - 8 * sizes[1][1], sizes[2][2] - 8 * sizes[2][1]
+    assert fixed_after < fixed_before // 2, sizes                  # (the lists' own parts; the arena has a floor of eight worst-case lists)
+    assert sizes[-1] == sizes[2]                                   # once
+    assert sizes[2][1] >= 8 * worst                                # the arena holds at least eight worst-case lists
+    assert eng.trim() == sizes[2][0]                               # (calling it again changes nothing)
+    eng.set_pool(pool)                                             # a new pool: the full reservation again
+    eng.step(sample(rng))
+    assert eng.variant()['run_cap'] == worst
     eng.close()
 
 

@@ -23,10 +23,10 @@ def apply(files, arg, replace_once):
                '                                                int sp_e0, row_spans& rs, uint32_t& err, unsigned long long (&xs)[5]) {\n  constexpr int NWA = SWB_NWA(NW);')
   replace_once(files, k, '    sm &= ~(1ull << s);\n    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)sp_a, s);',
                '    sm &= ~(1ull << s);\n    unsigned long long xprev = %s;\n    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)sp_a, s);' % T)
-  replace_once(files, k, '      if (min(mer, 64) <= ne * G) {\n',
-               '      const unsigned long long x1 = %s; xs[0] += x1 - xprev;\n      if (min(mer, 64) <= ne * G) {\n' % T)
-  replace_once(files, k, '      uint32_t carry = 0u;     // parity carried into the next word (all-ones or zero)\n',
-               '      const unsigned long long x2 = %s; xs[1] += x2 - x1;\n      uint32_t carry = 0u;\n' % T)
+  replace_once(files, k, '      if (packed) {\n        // the edges of this chunk',
+               '      const unsigned long long x1 = %s; xs[0] += x1 - xprev;\n      if (packed) {\n        // the edges of this chunk' % T)
+  replace_once(files, k, '      // masks -> coverage -> visible spans\n',
+               '      const unsigned long long x2 = %s; xs[1] += x2 - x1;\n' % T)
   replace_once(files, k, '      const uint32_t wbits = ((1u << nwords) - 1u) << wc;      // canvas words of this chunk\n      wave_sync();\n',
                '      const uint32_t wbits = ((1u << nwords) - 1u) << wc;\n      wave_sync();\n      const unsigned long long x3 = %s; xs[2] += x3 - x2;\n' % T)
   replace_once(files, k, '      }\n      }\n      wave_sync();\n    }\n    if (open_start >= 0) {',
