@@ -40,6 +40,8 @@ extern "C" {
 #define SWB_MAX_TASKS 8      /* sub-tasks of a MetaAggregated task              */
 #define SWB_MAX_SHAPES 32
 #define SWB_MAX_SHAPE_VERTS 64 /* per shape (reference max is 30, the "circle") */
+#define SWB_MAX_CUTS 4       /* thresholds per axis of a task filter that keys on position (see swb_task)          */
+#define SWB_MAX_CELLS ((SWB_MAX_CUTS + 1) * (SWB_MAX_CUTS + 1))
 
 enum swb_status {
   SWB_OK = 0,
@@ -92,6 +94,18 @@ typedef struct swb_task {
   double terminate_bonus;     /* both: _terminate_bonus                               */
   double termination_threshold;/* Clustering: _termination_threshold                  */
   double reward_range;        /* Clustering: _reward_range                            */
+  /* Filters / cluster distributions that key on POSITION (factors x, y): the reference evaluates
+   * `contains(sprite.factors)` at every step (tasks.py:134-137, 196-205) and a sprite's membership changes as it moves.
+   * Every position test of the reference's factor distributions is an interval test `lo <= v < hi`
+   * (factor_distributions.py:105-112), so membership is constant on the cells of the grid the tests' bounds cut the plane
+   * into: xcuts / ycuts are those bounds (ascending, as values of the position dtype: a bound compared with a float32
+   * position is rounded the way numpy compares it), a sprite at (x, y) is in cell
+   *   cy * (n_xcuts + 1) + cx,   cx = #{k : x >= xcuts[k]},  cy = #{k : y >= ycuts[k]},
+   * and its label this step is swb_pool::cell_label[entry][task][sprite][cell].  n_xcuts = n_ycuts = 0: the task does not
+   * key on position and swb_pool::label holds its labels. */
+  int32_t n_xcuts, n_ycuts;
+  double xcuts[SWB_MAX_CUTS];
+  double ycuts[SWB_MAX_CUTS];
 } swb_task;
 
 typedef struct swb_config {
@@ -127,11 +141,11 @@ typedef struct swb_config {
  *   rgb         = renderer _color_to_rgb(sprite.color)  (pil_renderer.py:82)
  *   label[t]    = FindGoal: filter_distrib.contains(factors) (tasks.py:134-137)
  *                 Clustering: first matching cluster index or -1 (tasks.py:196-205)
- *                 NOT SUPPORTED: filters keyed on x / y (or x_vel / y_vel).  The reference evaluates contains() at
- *                 every step; here membership is a label fixed per episode (re-evaluated only by swb_set_sprite_attr),
- *                 which is exact for every factor that cannot change inside an episode and wrong for position.
- *                 The Python lowering refuses such tasks (lowering.LoweringError); a C caller must do the same.
- *                 No shipped reference config filters on position.
+ *                 (evaluated once per episode: exact for every factor that cannot change inside an episode)
+ *   cell_label  for tasks whose filter / cluster distributions key on x or y (swb_task::n_xcuts / n_ycuts): the same label
+ *                 for every cell of the task's position grid, evaluated with the sprite's other factors -- the kernel
+ *                 looks the sprite's cell up at every step, as the reference re-evaluates contains() at every step.
+ *                 (Velocities are constant inside an episode: a filter on x_vel / y_vel is an ordinary label.)
  * Environment n draws entries pool_base[n] + (k mod pool_len[n]), k = 0,1,2...
  */
 typedef struct swb_pool {
@@ -147,6 +161,7 @@ typedef struct swb_pool {
   const int32_t* shape;       /* [P,S]  index into the uploaded shape table           */
   const uint8_t* rgb;         /* [P,S,4] (r,g,b,unused)                               */
   const int8_t* label;        /* [P,n_tasks,S]                                        */
+  const int8_t* cell_label;   /* [P,n_tasks,S,SWB_MAX_CELLS]; may be NULL when no task keys on position */
   const int32_t* pool_base;   /* [N]                                                  */
   const int32_t* pool_len;    /* [N]                                                  */
   const double* angle;        /* [P,S]   degrees; only for swb_factors (may be NULL)  */
@@ -298,8 +313,8 @@ int swb_evaluate(swb_handle h, uint8_t* success_dev, void* stream);
  * A handle starts with a list of max(4, max_sprites + 1) units of 8 bytes per canvas row for every environment and group of 64
  * output columns -- enough for ANY scene of convex sprites, about ten times what the usual scene needs (133 KB per environment
  * for 12 sprites at 128x128 with anti_aliasing 5).  This call, made once the handle has rendered a few typical steps, cuts every
- * list's own part down to 1.25 x the longest list of the last launch and adds a shared arena (a quarter of the parts together)
- * from which a list that outgrows its part continues; a scene that finds the arena exhausted too is flagged
+ * list's own part down to 1.25 x the longest list of the last launch and adds a shared arena (half of the parts together) into
+ * which a list that outgrows its part moves (a segment twice as large); a scene that finds the arena exhausted too is flagged
  * SWB_ENV_ERR_SPAN_OVERFLOW (never silent).  Results do not change.  Blocking (synchronises `stream`, reallocates); no-op when
  * called again.  swb_set_pool / swb_sample_pool restore the full reservation (the new pool may hold denser scenes).
  * run_cap_out (may be NULL): the units of a list's own part afterwards.  The Python engine calls it after its third
@@ -374,8 +389,9 @@ typedef struct swb_variant_info {
   int32_t resample_waves_per_simd; /* ... the resample / fill kernel */
   int32_t n_bands;            /* bands of output rows: waves of the second kernel per (environment, column group) */
   int32_t n_column_groups;    /* groups of 64 output columns */
-  int32_t run_cap;            /* the fixed part of a run list (8-byte units per environment and column group): 1.5 canvas heights,
-                               * 2 from nine sprites on; a list that outgrows it continues in segments of the shared arena */
+  int32_t run_cap;            /* a run list's own part (8-byte units per environment and column group): max(4, max_sprites + 1) per
+                               * canvas row until swb_trim_run_lists, then 1.25 x the longest list written; a list that outgrows
+                               * it moves to a segment of the shared arena */
   int32_t paint_in_cover;     /* 1: anti_aliasing = 1 and an image of up to 64 columns -- the cover kernel writes the frame
                                * itself and no second kernel is launched */
   int32_t arena_units;        /* units of the arena the run lists of all environments share for their overflow (0 until the first

@@ -56,6 +56,7 @@ def lib():
     _lib.swo_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     _lib.swo_contains_point.argtypes = [C.c_int] + [C.c_double] * 5
     _lib.swo_set_sprite_attr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    _lib.swo_set_sprite_cell_labels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     _lib.swo_get_sprite.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     set_shapes()
   return _lib
@@ -214,13 +215,19 @@ class Engine(object):
     y = np.ascontiguousarray(y, dtype=np.float64)
     lib().swo_set_positions(self._h, _p(x), _p(y))
 
-  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
-    """sprite.py:152-175 setters on a live sprite (attr: _abi.ATTR_SHAPE / ATTR_ANGLE / ATTR_SCALE)."""
+  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None, cell_label=None):
+    """sprite.py:152-175 setters on a live sprite (attr: _abi.ATTR_SHAPE / ATTR_ANGLE / ATTR_SCALE).  cell_label:
+    i8[n_tasks, SWB_MAX_CELLS] for tasks that key on position (swb_task::n_xcuts)."""
     d = None if delta is None else C.byref(C.c_double(float(delta)))
     lab = None if label is None else np.ascontiguousarray(label, dtype=np.int8)
     rc = lib().swo_set_sprite_attr(self._h, int(env), int(sprite), int(attr), float(value), d, _p(lab))
     if rc != 0:
       raise ValueError('swo_set_sprite_attr failed (%d)' % rc)
+    if cell_label is not None:
+      cells = np.ascontiguousarray(cell_label, dtype=np.int8)
+      rc = lib().swo_set_sprite_cell_labels(self._h, int(env), int(sprite), _p(cells))
+      if rc != 0:
+        raise ValueError('swo_set_sprite_cell_labels failed (%d)' % rc)
 
   def get_sprite(self, env, sprite):
     """dict(shape=index, angle, scale, path=f64[n,2]): the sprite as the oracle currently sees it."""

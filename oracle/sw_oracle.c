@@ -715,6 +715,7 @@ typedef struct {
   double *p_x, *p_y, *p_xv, *p_yv, *p_scale, *p_ca, *p_sa;
   uint8_t* p_rgb;
   int8_t* p_label;
+  int8_t* p_cell_label;   /* [P][T][S][SWB_MAX_CELLS]; NULL when no task keys on position */
   double* p_angle;   /* may be NULL */
   /* live */
   double *x, *y;
@@ -726,6 +727,7 @@ typedef struct {
   int32_t* ov_shape;  /* [N][S] */
   double *ov_scale, *ov_angle, *ov_cpath;   /* [N][S], [N][S], [N][S][SWB_MAX_SHAPE_VERTS][2] */
   int8_t* ov_label;   /* [N][T][S] */
+  int8_t* ov_cell_label;   /* [N][T][S][SWB_MAX_CELLS] (allocated by the first swo_set_sprite_cell_labels) */
 } swo_engine;
 
 /* The centred path of sprite s of environment i: as the setters left it, else fresh from the pool. */
@@ -764,6 +766,7 @@ swo_engine* swo_create(const swb_config* cfg, const swb_pool* pool) {
   e->p_sa = dup_mem(pool->sin_a, sizeof(double) * P * S);
   e->p_rgb = dup_mem(pool->rgb, (size_t)P * S * 4);
   e->p_label = dup_mem(pool->label, (size_t)P * T * S);
+  e->p_cell_label = pool->cell_label ? dup_mem(pool->cell_label, (size_t)P * T * S * SWB_MAX_CELLS) : NULL;
   e->p_angle = pool->angle ? dup_mem(pool->angle, sizeof(double) * P * S) : NULL;
   e->x = calloc((size_t)N * S, sizeof(double));
   e->y = calloc((size_t)N * S, sizeof(double));
@@ -786,6 +789,7 @@ void swo_destroy(swo_engine* e) {
   free(e->p_ca); free(e->p_sa); free(e->p_rgb); free(e->p_label);
   free(e->x); free(e->y); free(e->n); free(e->entry); free(e->step_count);
   free(e->episode); free(e->reset_next);
+  free(e->p_cell_label); free(e->ov_cell_label);
   free(e->p_angle); free(e->ov_flag); free(e->ov_shape); free(e->ov_scale); free(e->ov_angle); free(e->ov_cpath); free(e->ov_label);
   free(e);
 }
@@ -808,6 +812,31 @@ static void observe(swo_engine* e, int i, uint8_t* obs, uint8_t* succ_out, uint8
   double r = 0; int ok = 0;
   const int ov = e->ov_flag && e->ov_flag[i];
   const int8_t* label = ov ? e->ov_label + (size_t)i * c->n_tasks * S : e->p_label + (size_t)en * c->n_tasks * S;
+  /* tasks.py:134-137, 196-205: `contains(sprite.factors)` is evaluated at every step, and x / y are factors.  A task whose
+   * filter keys on position (swb_task::n_xcuts / n_ycuts) takes each sprite's label from the cell of the task's grid the sprite
+   * stands in NOW; the comparisons are numpy's (`v >= bound` with the bound already rounded to the position dtype). */
+  int8_t eff[SWB_MAX_TASKS * SWB_MAX_SPRITES];
+  int keyed = 0;
+  for (int t = 0; t < c->n_tasks; ++t) keyed |= (c->tasks[t].n_xcuts + c->tasks[t].n_ycuts) > 0;
+  if (keyed) {
+    const int T = c->n_tasks;
+    const int8_t* cells = (ov && e->ov_cell_label) ? e->ov_cell_label + (size_t)i * T * S * SWB_MAX_CELLS
+                                                    : e->p_cell_label + (size_t)en * T * S * SWB_MAX_CELLS;
+    for (int t = 0; t < T; ++t) {
+      const swb_task* tk = &c->tasks[t];
+      for (int s2 = 0; s2 < S; ++s2) {
+        int8_t v = label[t * S + s2];
+        if (tk->n_xcuts + tk->n_ycuts > 0 && s2 < n) {
+          int cx = 0, cy = 0;
+          for (int k = 0; k < tk->n_xcuts; ++k) cx += e->x[i * S + s2] >= tk->xcuts[k];
+          for (int k = 0; k < tk->n_ycuts; ++k) cy += e->y[i * S + s2] >= tk->ycuts[k];
+          v = cells[((size_t)t * S + s2) * SWB_MAX_CELLS + cy * (tk->n_xcuts + 1) + cx];
+        }
+        eff[t * S + s2] = v;
+      }
+    }
+    label = eff;
+  }
   const int err = eval_task(c, n, e->x + i * S, e->y + i * S, label, &r, &ok);
   if (task_reward) *task_reward = r;
   if (succ_out) *succ_out = (uint8_t)ok;
@@ -1008,6 +1037,7 @@ int swo_set_sprite_attr(swo_engine* e, int env, int sprite, int attr, double val
     e->ov_angle = calloc((size_t)N * S, sizeof(double));
     e->ov_cpath = calloc((size_t)N * S * SWB_MAX_SHAPE_VERTS * 2, sizeof(double));
     e->ov_label = calloc((size_t)N * T * S, 1);
+    if (e->p_cell_label) e->ov_cell_label = calloc((size_t)N * T * S * SWB_MAX_CELLS, 1);
   }
   const int en = e->entry[env];
   if (!e->ov_flag[env]) {                              /* materialise the episode's sprites from the pool */
@@ -1022,6 +1052,9 @@ int swo_set_sprite_attr(swo_engine* e, int env, int sprite, int attr, double val
       e->ov_angle[env * S + s] = e->p_angle[en * S + s];
     }
     memcpy(e->ov_label + (size_t)env * T * S, e->p_label + (size_t)en * T * S, (size_t)T * S);
+    if (e->ov_cell_label)
+      memcpy(e->ov_cell_label + (size_t)env * T * S * SWB_MAX_CELLS, e->p_cell_label + (size_t)en * T * S * SWB_MAX_CELLS,
+             (size_t)T * S * SWB_MAX_CELLS);
     e->ov_flag[env] = 1;
   }
   double* path = e->ov_cpath + ((size_t)env * S + sprite) * SWB_MAX_SHAPE_VERTS * 2;
@@ -1049,6 +1082,18 @@ int swo_set_sprite_attr(swo_engine* e, int env, int sprite, int attr, double val
   }
   memcpy(path, out, sizeof(double) * 2 * nv);
   if (label) for (int t = 0; t < T; ++t) e->ov_label[((size_t)env * T + t) * S + sprite] = label[t];
+  return 0;
+}
+
+/* After swo_set_sprite_attr on a sprite of a task that keys on position: its labels per cell of the task's grid, re-evaluated
+ * by the caller with the new attribute (cells: i8[n_tasks][SWB_MAX_CELLS]). */
+int swo_set_sprite_cell_labels(swo_engine* e, int env, int sprite, const int8_t* cells) {
+  const swb_config* c = &e->cfg;
+  const int S = c->max_sprites, T = c->n_tasks;
+  if (env < 0 || env >= c->n_envs || !e->ov_flag || !e->ov_flag[env] || !e->ov_cell_label || !cells) return -1;
+  if (sprite < 0 || sprite >= e->n[env]) return -1;
+  for (int t = 0; t < T; ++t)
+    memcpy(e->ov_cell_label + (((size_t)env * T + t) * S + sprite) * SWB_MAX_CELLS, cells + (size_t)t * SWB_MAX_CELLS, SWB_MAX_CELLS);
   return 0;
 }
 

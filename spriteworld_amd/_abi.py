@@ -6,6 +6,8 @@ SWB_MAX_TASKS = 8
 SWB_MAX_SHAPES = 32
 SWB_MAX_SHAPE_VERTS = 64
 SWB_MAX_GROUPS = 8
+SWB_MAX_CUTS = 4
+SWB_MAX_CELLS = (SWB_MAX_CUTS + 1) * (SWB_MAX_CUTS + 1)
 SWB_MAX_CANDIDATES = 12
 
 # enum swb_action_space
@@ -34,6 +36,10 @@ class SwbTask(C.Structure):
       ('terminate_bonus', C.c_double),
       ('termination_threshold', C.c_double),
       ('reward_range', C.c_double),
+      ('n_xcuts', C.c_int32),
+      ('n_ycuts', C.c_int32),
+      ('xcuts', C.c_double * SWB_MAX_CUTS),
+      ('ycuts', C.c_double * SWB_MAX_CUTS),
   ]
 
 
@@ -75,6 +81,7 @@ class SwbPool(C.Structure):
       ('shape', C.c_void_p),
       ('rgb', C.c_void_p),
       ('label', C.c_void_p),
+      ('cell_label', C.c_void_p),
       ('pool_base', C.c_void_p),
       ('pool_len', C.c_void_p),
       ('angle', C.c_void_p),

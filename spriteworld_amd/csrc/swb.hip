@@ -251,9 +251,10 @@ int ensure_handoff_tables(swb_engine* h, bool need_lists = true) {
   // come from, then 4 units of slack (the resample kernel reads a run's first 16 bytes in one go)
   if (!h->d_runs && need_lists) {
     const size_t fixed = (size_t)p.N * p.ncg * p.run_cap;
-    // arena: a quarter of the fixed parts once they have been trimmed (before that they hold any scene of convex sprites by
-    // themselves), and at least eight worst-case lists
-    size_t arena = std::max(h->lists_trimmed ? fixed / 4 : (size_t)0, (size_t)8 * h->run_cap_worst);
+    // arena (a list that outgrows its own part moves there, into a segment twice as large): half of the own parts together once
+    // they have been trimmed (before that they hold any scene of convex sprites by themselves), and at least eight worst-case
+    // lists -- sixteen times their size, a moved list's segment being a power of two times its own part
+    size_t arena = std::max(h->lists_trimmed ? fixed / 2 : (size_t)0, (size_t)16 * h->run_cap_worst);
     if (h->arena_override >= 0) arena = (size_t)h->arena_override;
     const size_t units = fixed + arena + 4;
     if (units * 8 >= ((size_t)1 << 32))                                  // (list positions are 32-bit byte offsets)
@@ -270,7 +271,6 @@ int ensure_handoff_tables(swb_engine* h, bool need_lists = true) {
     p.arena_head = h->d_arena_head;
     p.arena_base = (int64_t)fixed;
     p.arena_units = (int32_t)std::min(arena, (size_t)0x7fffffff);
-    p.arena_chunk = std::max(16, p.run_cap / 2);
   }
   h->tables_dirty = false;
   return 0;

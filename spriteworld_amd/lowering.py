@@ -14,7 +14,9 @@ reference's own classes or the mirrors in this package -- and produces
                   task membership label of each sprite (tasks.py:134-137,
                   196-205 evaluate `contains(sprite.factors)` every step, but
                   `step()` only ever changes x and y, so for factor filters that
-                  do not key on x/y the result is fixed at reset).
+                  do not key on x/y the result is fixed at reset; for filters that
+                  do, the label is tabulated over the cells of the grid their
+                  interval bounds cut the plane into and looked up every step).
 """
 import ctypes as C
 import math
@@ -36,9 +38,10 @@ def _cls(obj):
 # --------------------------------------------------------------------------- #
 # Config                                                                       #
 # --------------------------------------------------------------------------- #
-def _lower_task(task, out):
+def _lower_task(task, out, pos_is_f32=True):
   """Fills one SwbTask from a FindGoalPosition / Clustering / NoReward object."""
   name = _cls(task)
+  out.n_xcuts = out.n_ycuts = 0
   if name == 'NoReward':
     out.kind = _abi.TASK_NO_REWARD
   elif name == 'FindGoalPosition':
@@ -61,6 +64,13 @@ def _lower_task(task, out):
     out.sparse_reward = int(bool(task._sparse_reward))
   else:
     raise LoweringError('unsupported task type: ' + name)
+  if name in ('FindGoalPosition', 'Clustering'):
+    xcuts, ycuts = position_cuts(task, pos_is_f32)
+    out.n_xcuts, out.n_ycuts = len(xcuts), len(ycuts)
+    for k, v in enumerate(xcuts):
+      out.xcuts[k] = v
+    for k, v in enumerate(ycuts):
+      out.ycuts[k] = v
 
 
 _AGG = {'nansum': _abi.AGG_SUM, 'nanmax': _abi.AGG_MAX, 'nanmin': _abi.AGG_MIN,
@@ -68,23 +78,113 @@ _AGG = {'nansum': _abi.AGG_SUM, 'nanmax': _abi.AGG_MAX, 'nanmin': _abi.AGG_MIN,
 _TERM = {'all': _abi.TERM_ALL, 'any': _abi.TERM_ANY}
 
 
-def check_static_labels(task):
-  """Filters and cluster distributions are evaluated once per episode (pool label), which is only the
-  reference's per-step `contains(sprite.factors)` (tasks.py:134-137, 196-204) if they never look at a
-  factor that changes inside an episode: raises when one keys on x or y."""
-  for sub in subtasks_of(task):
-    dists = []
-    if _cls(sub) == 'FindGoalPosition' and sub._filter_distrib is not None:
-      dists.append(sub._filter_distrib)
-    elif _cls(sub) == 'Clustering':
-      dists.extend(sub._cluster_distribs)
-    for d in dists:
-      keys = getattr(d, 'keys', None)
-      keys = set(keys() if callable(keys) else (keys or ()))
-      moving = sorted(keys & {'x', 'y'})
-      if moving:
-        raise LoweringError('task filter / cluster distribution keys on %s, which change during an episode: '
-                            'membership cannot be fixed at reset (step this task with the CPU reference)' % moving)
+_POSITION_KEYS = ('x', 'y')
+
+
+def _task_distribs(sub):
+  name = _cls(sub)
+  if name == 'FindGoalPosition':
+    return [sub._filter_distrib] if sub._filter_distrib is not None else []
+  if name == 'Clustering':
+    return list(sub._cluster_distribs)
+  return []
+
+
+def _collect_position_bounds(d, out):
+  """Every bound of an interval test on x / y in a factor-distribution tree (the reference's classes or the mirrors):
+  Continuous.contains is `minval <= v < maxval` (factor_distributions.py:105-112); Product / Mixture / Intersection hold
+  `components`, SetMinus `base` + `hold_out`, Selection `base` + `filtering`."""
+  if d is None:
+    return
+  key = getattr(d, 'key', None)
+  if key is not None and hasattr(d, 'minval') and hasattr(d, 'maxval'):
+    if key in _POSITION_KEYS:
+      out[key].extend([d.minval, d.maxval])
+    return
+  if key is not None and hasattr(d, 'candidates'):
+    if key in _POSITION_KEYS:
+      raise LoweringError('a Discrete distribution over %r in a task filter (membership by equality with a position) is not '
+                          'supported' % key)
+    return
+  kids = list(getattr(d, 'components', ()) or ())
+  for attr in ('base', 'hold_out', 'filtering'):
+    if getattr(d, attr, None) is not None:
+      kids.append(getattr(d, attr))
+  if not kids:
+    keys = getattr(d, 'keys', None)
+    keys = set(keys() if callable(keys) else (keys or ()))
+    if keys & set(_POSITION_KEYS):
+      raise LoweringError('task filter of type %s keys on position and is not a composition of Continuous distributions' % _cls(d))
+  for k in kids:
+    _collect_position_bounds(k, out)
+
+
+def _threshold(bound, pos_is_f32):
+  """The smallest position value v (a float32 when positions are float32) for which numpy's `v >= bound` holds -- `v < bound`
+  is its negation under the same rule.  NEP 50: a Python number compared with an np.float32 is first cast to float32; an
+  np.float64 bound promotes the comparison to float64."""
+  if not pos_is_f32:
+    return float(bound)
+  if isinstance(bound, (np.floating, np.ndarray)) and np.asarray(bound).dtype == np.float64:
+    b = np.float64(bound)
+    t = np.float32(b)
+    if np.float64(t) < b:
+      t = np.nextafter(t, np.float32(np.inf), dtype=np.float32)
+    return float(t)
+  return float(np.float32(bound))
+
+
+def position_cuts(sub, pos_is_f32):
+  """(xcuts, ycuts): the ascending thresholds that the position tests of a (sub-)task's filter / cluster distributions cut
+  the two axes at; ([], []) when it does not key on position.  See swb_task in include/swb.h."""
+  out = {'x': [], 'y': []}
+  for d in _task_distribs(sub):
+    _collect_position_bounds(d, out)
+  cuts = []
+  for key in _POSITION_KEYS:
+    vals = sorted(set(_threshold(b, pos_is_f32) for b in out[key]))
+    vals = [v for v in vals if not math.isnan(v)]
+    if len(vals) > _abi.SWB_MAX_CUTS:
+      raise LoweringError('task filter tests %s against %d different bounds (at most %d supported)' % (key, len(vals), _abi.SWB_MAX_CUTS))
+    cuts.append(vals)
+  return cuts[0], cuts[1]
+
+
+def _label_from_factors(sub, factors):
+  name = _cls(sub)
+  if name == 'FindGoalPosition':
+    f = sub._filter_distrib
+    return int(f is None or bool(f.contains(factors)))
+  if name == 'Clustering':
+    for ci, distrib in enumerate(sub._cluster_distribs):
+      if distrib.contains(factors):
+        return ci
+    return -1
+  return 0
+
+
+def cell_labels_of(sub, sprite, xcuts, ycuts, pos_dtype):
+  """i8[SWB_MAX_CELLS]: the sprite's label in every cell of the task's position grid -- the reference's own
+  `contains(sprite.factors)` evaluated with x / y at a representative of the cell (its lower-left corner; -inf below the
+  first cut), the other factors as the sprite holds them.  Self-checked against direct evaluation at random positions."""
+  cells = np.zeros(_abi.SWB_MAX_CELLS, np.int8)
+  factors = dict(sprite.factors)
+  reps_x = [pos_dtype(-np.inf)] + [pos_dtype(v) for v in xcuts]
+  reps_y = [pos_dtype(-np.inf)] + [pos_dtype(v) for v in ycuts]
+  nx = len(xcuts) + 1
+  for cy, vy in enumerate(reps_y):
+    for cx, vx in enumerate(reps_x):
+      factors['x'], factors['y'] = vx, vy
+      cells[cy * nx + cx] = _label_from_factors(sub, factors)
+  rng = np.random.RandomState(12345)
+  for _ in range(16):
+    vx, vy = pos_dtype(rng.uniform(-0.2, 1.2)), pos_dtype(rng.uniform(-0.2, 1.2))
+    factors['x'], factors['y'] = vx, vy
+    cx = sum(1 for c in xcuts if float(vx) >= c)
+    cy = sum(1 for c in ycuts if float(vy) >= c)
+    if _label_from_factors(sub, factors) != cells[cy * nx + cx]:
+      raise LoweringError('task filter is not a function of the position grid its Continuous bounds define (at x=%r, y=%r)' % (vx, vy))
+  return cells
 
 
 def subtasks_of(task):
@@ -114,7 +214,6 @@ def lower_config(task, action_space, renderers, keep_in_frame=True, max_episode_
   np.float32 (what its `action_spec()` declares); numpy's promotion rules make the two
   differ in the last bits of motions, click offsets and some rewards, so the engine follows
   whichever the caller uses.  Ignored for Embodied (integer actions)."""
-  check_static_labels(task)
   cfg = _abi.SwbConfig()
   cfg.n_envs = int(num_envs)
   cfg.max_sprites = int(max_sprites)
@@ -164,7 +263,7 @@ def lower_config(task, action_space, renderers, keep_in_frame=True, max_episode_
     cfg.meta_aggregator, cfg.meta_termination = _AGG[agg], _TERM[term]
     cfg.meta_terminate_bonus = float(task._terminate_bonus)
   for i, sub in enumerate(subs):
-    _lower_task(sub, cfg.tasks[i])
+    _lower_task(sub, cfg.tasks[i], pos_is_f32=bool(pos_is_f32))
   return cfg
 
 
@@ -188,6 +287,7 @@ class Pool(object):
     self.shape = np.zeros((P, S), np.int32)
     self.rgb = np.zeros((P, S, 4), np.uint8)
     self.label = np.zeros((P, T, S), np.int8)
+    self.cell_label = None      # i8[P, T, S, SWB_MAX_CELLS] when a task keys on position (swb_task::n_xcuts), else None
     self.pool_base = None
     self.pool_len = None
     # Not consumed by the kernels; kept for SpriteFactors-style observations.
@@ -223,6 +323,10 @@ class Pool(object):
     s.angle, s.color = self.angle.ctypes.data, self.color.ctypes.data
     self.attr_f32 = np.ascontiguousarray(self.attr_f32, dtype=np.uint8)
     s.attr_f32 = self.attr_f32.ctypes.data
+    if self.cell_label is not None:
+      self.cell_label = np.ascontiguousarray(self.cell_label, dtype=np.int8)
+      assert self.cell_label.shape == (self.n_entries, self.n_tasks, self.max_sprites, _abi.SWB_MAX_CELLS)
+      s.cell_label = self.cell_label.ctypes.data
     return s
 
 
@@ -257,12 +361,16 @@ def position_dtype(episodes):
 
 def lower_episodes(episodes, task, renderers, max_sprites=None):
   """List of sprite lists (one per reset, back-to-front order) -> Pool."""
-  check_static_labels(task)
   subs = subtasks_of(task)
+  pos_dtype = position_dtype(episodes).type
+  cuts = [position_cuts(sub, pos_dtype == np.float32) for sub in subs]
+  keyed = [bool(xc or yc) for xc, yc in cuts]
   _, pil = find_pil_renderer(renderers)
   to_rgb = pil._color_to_rgb if pil is not None else (lambda c: (0, 0, 0))
   S = max_sprites or max([len(ep) for ep in episodes] + [1])
   pool = Pool(len(episodes), S, len(subs))
+  if any(keyed):
+    pool.cell_label = np.zeros((len(episodes), len(subs), S, _abi.SWB_MAX_CELLS), np.int8)
   for e, ep in enumerate(episodes):
     if len(ep) > S:
       raise LoweringError('episode %d has %d sprites > max_sprites %d' % (e, len(ep), S))
@@ -284,4 +392,6 @@ def lower_episodes(episodes, task, renderers, max_sprites=None):
       pool.color[e, s] = [float(c) for c in sp.color]
       for t, sub in enumerate(subs):
         pool.label[e, t, s] = _label_of(sub, sp)
+        if keyed[t]:       # membership by position: the label in every cell of the task's grid (looked up every step)
+          pool.cell_label[e, t, s] = cell_labels_of(sub, sp, cuts[t][0], cuts[t][1], pos_dtype)
   return pool

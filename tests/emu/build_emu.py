@@ -52,7 +52,7 @@ def _rewrite(text, name):
   assert text.count(anchor) == 1, anchor
   text = text.replace(anchor, ok_fn + anchor)
   anchor = 'rec = *reinterpret_cast<cptr<swb_u4>>(runs + uo);'
-  assert text.count(anchor) == 3, anchor
+  assert text.count(anchor) == 2, anchor
   text = text.replace(anchor, anchor + ' emu_check(emu_list_unit_ok(p, env, g, uo >> 3));')
   anchor = 'hd = runs[2 * u]; s0 = runs[2 * u + 1];'
   assert text.count(anchor) == 1, anchor

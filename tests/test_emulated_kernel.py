@@ -225,11 +225,12 @@ def test_emulated_kernel_run_list_overflow_is_flagged(monkeypatch, run_cap, band
 
 @pytest.mark.parametrize('run_cap,bands,arena', [(8, 1, 1 << 20), (8, 4, 1 << 20), (12, 8, 1 << 20), (40, 2, 1 << 20), (24, 1, 600)])
 def test_emulated_kernel_run_lists_continue_in_the_shared_arena(monkeypatch, run_cap, bands, arena):
-  """Round 6: a run list owns a small fixed part and continues in segments of a shared arena (jump units) when it outgrows
-  it.  With a fixed part of 8 .. 40 units EVERY list jumps, several times: frames, state and rewards stay bit-exact on both
-  second kernels (resample: anti_aliasing 5; fill: anti_aliasing 1 on a wide image), no environment is flagged, and no run
-  record is read outside the list's own part or the arena.  With an arena too small for the batch (600 units) the
-  environments that find it exhausted are FLAGGED and every other one is still exact."""
+  """Round 6: a run list owns a part of its own and MOVES to a segment of a shared arena, twice (four times ...) as large, when
+  it outgrows it (the wave copies what it wrote; positions in the header are counted from the own part, so the second kernels
+  know nothing of it).  With an own part of 8 .. 40 units EVERY list moves, several times: frames, state and rewards stay
+  bit-exact on both second kernels (resample: anti_aliasing 5; fill: anti_aliasing 1 on a wide image) for every band count, no
+  environment is flagged, and no run record is read outside the list's own part or the arena.  With an arena too small for
+  the batch (600 units) the environments that find it exhausted are FLAGGED and every other one is still exact."""
   import ctypes as C
   from oracle import oracle
   from spriteworld_amd import _abi
@@ -269,7 +270,7 @@ def test_emulated_kernel_run_lists_continue_in_the_shared_arena(monkeypatch, run
 def test_emulated_run_lists_are_trimmed_after_the_third_rendering_launch():
   """The lists start with room for any scene of convex sprites (max(4, S + 1) units per canvas row); after the third rendering
   launch the engine cuts them to 1.25 x the longest list written + a shared arena (swb_trim_run_lists).  Frames stay exact
-  before, at and after the cut; a scene that later grows beyond its part continues in the arena; a new pool restores the
+  before, at and after the cut; a list that later outgrows its part moves to the arena; a new pool restores the
   reservation."""
   from oracle import oracle
   for name, n_envs, aa in (('embodied_s12', 3, 5), ('cluster_s5', 6, 5), ('geom_160x48', 3, 1)):
@@ -292,7 +293,7 @@ def test_emulated_run_lists_are_trimmed_after_the_third_rendering_launch():
     fixed_before, fixed_after = sizes[1][2] - 8 * sizes[1][1], sizes[2][2] - 8 * sizes[2][1]
     assert fixed_after < fixed_before // 2, sizes                  # (the lists' own parts; the arena has a floor of eight worst-case lists)
     assert sizes[-1] == sizes[2]                                   # once
-    assert sizes[2][1] >= 8 * worst                                # the arena holds at least eight worst-case lists
+    assert sizes[2][1] >= 16 * worst                               # the arena: at least sixteen worst-case lists
     assert eng.trim() == sizes[2][0]                               # (calling it again changes nothing)
     eng.set_pool(pool)                                             # a new pool: the full reservation again
     eng.step(sample(rng))

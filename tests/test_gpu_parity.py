@@ -232,11 +232,53 @@ def test_without_cost_ordered_dispatch(monkeypatch):
 def test_run_list_overflow_is_flagged(monkeypatch):
   from spriteworld_amd import _abi, engine
   monkeypatch.setenv('SWB_RUN_CAP', '24')
+  monkeypatch.setenv('SWB_ARENA_UNITS', '0')             # (no arena for an outgrown list to move to)
   cfg, pool, sample = workloads.build('cluster_s5', 64, episodes_per_env=2, seed=0, anti_aliasing=5)
   eng = engine.Engine(cfg, pool)
   eng.step(sample(np.random.default_rng(0)))
   assert (eng.outputs_host()['error'] & _abi.ENV_ERR_SPAN_OVERFLOW).all()
   eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('run_cap,bands', [(8, 1), (12, 4), (40, 2), (64, 8)])
+def test_run_lists_that_outgrow_their_part_move_to_the_arena(monkeypatch, run_cap, bands):
+  """Round 6: with an own part of 8 .. 64 units every run list outgrows it and moves to a segment of the shared arena (several
+  times); nothing changes in what the step returns -- both second kernels (resample, fill), every band count, 12 sprites at
+  128x128 included."""
+  monkeypatch.setenv('SWB_RUN_CAP', str(run_cap))
+  monkeypatch.setenv('SWB_ARENA_UNITS', str(1 << 22))
+  monkeypatch.setenv('SWB_BANDS', str(bands))
+  _run('cluster_s5', 96, 4, 5)
+  _run('embodied_s12', 24, 3, 5)
+  monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')
+  _run('geom_160x48', 33, 3, 1)
+
+
+@pytest.mark.gpu
+def test_run_lists_are_trimmed_after_the_third_rendering_launch():
+  """The hand-off lists start with room for any scene of convex sprites and are cut to 1.25 x the longest list written (+ the
+  arena) by the engine's third rendering step; frames stay exact across the cut (compared with the oracle every step)."""
+  from oracle import oracle
+  from spriteworld_amd import engine
+  for name, n_envs in (('embodied_s12', 256), ('cluster_s5', 1024)):
+    cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=3, seed=4, anti_aliasing=5)
+    eng, ora = engine.Engine(cfg, pool), oracle.Engine(cfg, pool)
+    rng = np.random.default_rng(8)
+    sizes = []
+    for t in range(6):
+      a = sample(rng)
+      want = ora.step(a)
+      eng.step(a)
+      got = eng.outputs_host()
+      assert not got['error'].any()
+      assert np.array_equal(got['obs'], want['obs']), (name, t)
+      v = eng.variant()
+      sizes.append((v['run_cap'], v['run_list_bytes']))
+    worst = max(4, cfg.max_sprites + 1) * cfg.anti_aliasing * cfg.image_w + 1
+    assert sizes[0][0] == sizes[1][0] == worst and sizes[2][0] < worst // 2 and sizes[-1] == sizes[2], sizes
+    assert sizes[2][1] < sizes[1][1] // 2, sizes
+    eng.close()
 
 
 @pytest.mark.parametrize('name,n_envs', [('cluster_s5', 64), ('tiny_s6', 48), ('wide_s4', 32), ('ragged_s16', 96)])

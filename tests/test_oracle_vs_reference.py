@@ -336,3 +336,60 @@ def test_randomised_reference_configurations(seed):
     assert n == len(pos)
     assert np.array_equal(pos[:, 0], st['x'][0, :n]) and np.array_equal(pos[:, 1], st['y'][0, :n]), t
     assert np.array_equal(ts.observation['image'], out['obs'][0]), t
+
+
+@pytest.mark.parametrize('f32', [True, False], ids=['f32pos', 'f64pos'])
+@pytest.mark.parametrize('name', __import__('tests._position_cases', fromlist=['CASES']).CASES)
+def test_tasks_that_filter_on_position_match_the_reference(name, f32):
+  """Round 6: filters / cluster distributions keyed on x, y (the reference evaluates `contains(sprite.factors)` at EVERY step,
+  tasks.py:134-137, 196-205).  The lowering tabulates each sprite's label over the cells the filter's interval bounds cut the
+  plane into (with the reference's own contains()), the oracle looks the sprite's cell up every step: rewards, success, step
+  types bit for bit against the unmodified reference while sprites are dragged across the cuts and clipped onto the frame
+  (x = 0.0 / 1.0 exactly: the half-open bounds), float32 and float64 positions, Python-float and np.float64 bounds."""
+  ref_harness.load_reference()
+  from spriteworld import environment
+  from spriteworld import renderers as ref_renderers
+  from oracle import oracle
+  from spriteworld_amd import _abi, lowering
+  from tests import _position_cases as pc
+  ns = pc.namespace_of_reference()
+  task, aspace, rends, keep, max_len = pc.environment_parts(ns, name)
+  episodes = pc.episodes_of(ns, name, f32)
+  assert (lowering.position_dtype(episodes) == np.float32) == f32
+  cfg = lowering.lower_config(task, aspace, rends, keep, max_len, 1, pc.N_SPRITES, pos_is_f32=f32)
+  assert sum(cfg.tasks[t].n_xcuts + cfg.tasks[t].n_ycuts for t in range(cfg.n_tasks)) > 0
+  pool = lowering.lower_episodes(episodes, task, rends, max_sprites=pc.N_SPRITES).assign_round_robin(1)
+  assert pool.cell_label is not None
+  eng = oracle.Engine(cfg, pool)
+  it = _fresh_episodes(episodes)
+  env = environment.Environment(task=task, action_space=aspace, renderers=dict(rends, success=ref_renderers.Success()),
+                                init_sprites=lambda: next(it), keep_in_frame=keep, max_episode_length=max_len)
+  rng = np.random.RandomState(77)
+  changed = 0
+  prev = None
+  for t in range(300):
+    a = rng.uniform(0, 1, 4)
+    if t % 3 == 0:            # click ON a sprite, so that something moves most steps
+      s = env._sprites[rng.randint(len(env._sprites))]
+      a[:2] = np.asarray(s.position, dtype=np.float64)
+    try:
+      ts = env.step(a)
+    except (ValueError, ZeroDivisionError) as e:      # Davies-Bouldin with one cluster left / a zero score: the oracle flags it
+      out = eng.step(a[None])
+      want = _abi.ENV_ERR_DB_LABELS if isinstance(e, ValueError) else _abi.ENV_ERR_DB_ZERO
+      assert out['error'][0] & want, (t, e)
+      break
+    out = eng.step(a[None])
+    assert int(ts.step_type) == int(out['step_type'][0]), t
+    r = np.nan if ts.reward is None else float(ts.reward)
+    assert (np.isnan(r) and np.isnan(out['reward'][0])) or _bits(r) == _bits(out['reward'][0]), (t, r, out['reward'][0])
+    assert bool(ts.observation['success']) == bool(out['success'][0]), t
+    assert np.array_equal(ts.observation['image'], out['obs'][0]), t
+    # how often membership really changed inside an episode (the case must exercise what it is for)
+    subs = lowering.subtasks_of(task)
+    lab = tuple(lowering._label_of(sub, s) for sub in subs for s in env._sprites)    # pylint: disable=protected-access
+    if prev is not None and int(ts.step_type) == 1 and lab != prev:
+      changed += 1
+    prev = lab
+  else:
+    assert changed >= 5, changed
