@@ -610,8 +610,11 @@ def main():
     }.items():
       extra_runs.append((label, TimedRun(nm, n, short, 5, aa, device).build()))
     # the headline batch as two groups of 4096 on two HIP streams: consecutive steps of different groups overlap,
-    # which hides the fill/drain of each launch (an application-level choice; `value` is one launch per step)
-    extra_runs.append(('%s_2_groups_2_streams' % args.workload, GroupsRun(args.workload, args.envs_per_gpu, 2, short, 5, args.aa, device).build()))
+    # which hides part of the fill/drain of each launch: +5 % for the same total work (profiles/r06_queue_concurrency.md; an
+    # application-level choice -- environment.EnvironmentGroups -- `value` is one launch per step).  At least 100 steps: the
+    # two queues need a few launches to interleave, and this figure is wall time over host-side launches
+    extra_runs.append(('%s_2_groups_2_streams' % args.workload,
+                       GroupsRun(args.workload, args.envs_per_gpu, 2, max(args.steps, 100), 20, args.aa, device).build()))
 
   extra_error = []
 

@@ -365,6 +365,11 @@ int swb_set_sprite_attr(swb_handle h, int32_t env, int32_t sprite, int32_t attr,
 /* The sprite as the engine currently sees it: shape index, angle, scale, and its centred path
  * (Sprite._centered_path.vertices, sprite.py:96-101) -- path_xy f64[SWB_MAX_SHAPE_VERTS][2], n_verts
  * entries written.  Any output pointer may be NULL.  Blocking. */
+/* After swb_set_sprite_attr on a handle with tasks that key on position (swb_task::n_xcuts / n_ycuts): the sprite's labels
+ * per cell of each task's grid, re-evaluated by the caller with the new attribute -- cells i8[n_tasks][SWB_MAX_CELLS], laid
+ * out as swb_pool::cell_label.  Without the call the sprite keeps the per-cell labels of its pool entry.  Blocking. */
+int swb_set_sprite_cell_labels(swb_handle h, int32_t env, int32_t sprite, const int8_t* cells, void* stream);
+
 int swb_get_sprite(swb_handle h, int32_t env, int32_t sprite, int32_t* shape, double* angle, double* scale, int32_t* n_verts,
                    double* path_xy, void* stream);
 

@@ -19,7 +19,7 @@ EXPORTS = (
     'swb_upload_resample', 'swb_set_pool', 'swb_sample_pool', 'swb_resample_pool', 'swb_get_pool', 'swb_reset_all', 'swb_step', 'swb_render', 'swb_evaluate', 'swb_factors',
     'swb_get_state', 'swb_set_positions', 'swb_variant', 'swb_build_id', 'swb_timing_enable', 'swb_step_time_ms',
     'swb_set_sprite_attr', 'swb_get_sprite', 'swb_sprite_path_op', 'swb_kernel_times_ms', 'swb_get_env_state',
-    'swb_get_sprite_types', 'swb_trim_run_lists',
+    'swb_get_sprite_types', 'swb_trim_run_lists', 'swb_set_sprite_cell_labels',
 )
 
 _lib = None
@@ -62,6 +62,7 @@ def load():
   lib.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   if hasattr(lib, 'swb_trim_run_lists') or not os.environ.get('SWB_LIBRARY'):
     lib.swb_trim_run_lists.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+    lib.swb_set_sprite_cell_labels.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
   lib.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
   lib.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
   lib.swb_get_env_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]

@@ -80,6 +80,8 @@ struct swb_engine {
   int32_t* d_p_shape = nullptr;
   uint32_t* d_p_rgb = nullptr;
   int8_t* d_p_label = nullptr;
+  int8_t* d_p_cell_label = nullptr;  // swb_pool::cell_label (tasks that key on position)
+  bool keyed = false;                // some task's filter keys on position (swb_task::n_xcuts / n_ycuts)
   uint8_t* d_p_attr = nullptr;       // swb_pool::attr_f32
   int32_t *d_pool_base = nullptr, *d_pool_len = nullptr;
   double *d_p_angle = nullptr, *d_p_color = nullptr;
@@ -111,6 +113,7 @@ struct swb_engine {
   int32_t* d_ov_shape = nullptr;
   double *d_ov_scale = nullptr, *d_ov_angle = nullptr, *d_ov_cpath = nullptr;
   int8_t* d_ov_label = nullptr;
+  int8_t* d_ov_cell_label = nullptr;
   // timing
   bool timing = false;
   struct step_events { hipEvent_t e0, e1, e2; };     // before cover, between the kernels, after resample / fill
@@ -472,6 +475,16 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   p.n_tasks = cfg->n_tasks; p.is_meta = cfg->is_meta; p.meta_aggregator = cfg->meta_aggregator;
   p.meta_termination = cfg->meta_termination; p.meta_terminate_bonus = cfg->meta_terminate_bonus;
   memcpy(p.tasks, cfg->tasks, sizeof(p.tasks));
+  for (int t = 0; t < cfg->n_tasks; ++t) {
+    const swb_task& tk = cfg->tasks[t];
+    if (tk.n_xcuts < 0 || tk.n_xcuts > SWB_MAX_CUTS || tk.n_ycuts < 0 || tk.n_ycuts > SWB_MAX_CUTS) {
+      delete h;
+      return fail(SWB_ERR_INVALID, "task %d: between 0 and %d position thresholds per axis supported", t, SWB_MAX_CUTS);
+    }
+    for (int k = 1; k < tk.n_xcuts; ++k) if (!(tk.xcuts[k - 1] < tk.xcuts[k])) { delete h; return fail(SWB_ERR_INVALID, "task %d: xcuts must ascend", t); }
+    for (int k = 1; k < tk.n_ycuts; ++k) if (!(tk.ycuts[k - 1] < tk.ycuts[k])) { delete h; return fail(SWB_ERR_INVALID, "task %d: ycuts must ascend", t); }
+    if (tk.n_xcuts + tk.n_ycuts > 0) h->keyed = true;
+  }
   if (p.Wc > 1023 || p.Hc > 65535) { delete h; return fail(SWB_ERR_INVALID, "canvas %dx%d too large", p.Wc, p.Hc); }
   if (!pick_variant(p.Wc)) { delete h; return fail(SWB_ERR_INVALID, "canvas width %d not supported", p.Wc); }
   if (p.Wo > 64 * SWB_MAX_CG) { delete h; return fail(SWB_ERR_INVALID, "image width %d not supported (max %d)", p.Wo, 64 * SWB_MAX_CG); }
@@ -573,7 +586,7 @@ int swb_destroy(swb_handle h) {
     for (auto& ev : *list) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); (void)hipEventDestroy(ev.e2); }
   void* bufs[] = {h->d_shape_verts, h->d_shape_dmin, h->d_shape_off, h->d_h_xmin, h->d_h_cnt, h->d_h_tbl, h->d_h_pfx, h->d_v_tab,
                   h->d_v_pfx, h->d_v_end, h->d_p_n, h->d_p_x, h->d_p_y, h->d_p_xv, h->d_p_yv, h->d_p_scale, h->d_p_ca, h->d_p_sa,
-                  h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_p_attr, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
+                  h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_p_cell_label, h->d_ov_cell_label, h->d_p_attr, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
                   h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler,
                   h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label,
                   h->d_cost_cnt, h->d_cost_list, h->d_ccost_list, h->d_runs, h->d_rhdr, h->d_arena_head, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
@@ -726,6 +739,10 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
   rc |= upload(&h->d_p_shape, pool->shape, PS);
   rc |= upload(&h->d_p_rgb, rgb.data(), PS);
   rc |= upload(&h->d_p_label, pool->label, (size_t)P * T * S);
+  if (h->keyed) {
+    if (!pool->cell_label) return fail(SWB_ERR_INVALID, "a task of this handle keys on position (swb_task::n_xcuts / n_ycuts): swb_pool::cell_label is required");
+    rc |= upload(&h->d_p_cell_label, pool->cell_label, (size_t)P * T * S * SWB_MAX_CELLS);
+  }
   rc |= upload(&h->d_p_attr, pool->attr_f32, PS);                      // (NULL: zeros = Python numbers)
   rc |= upload(&h->d_pool_base, pool->pool_base, N);
   rc |= upload(&h->d_pool_len, pool->pool_len, N);
@@ -738,6 +755,7 @@ int swb_set_pool(swb_handle h, const swb_pool* pool) {
   p.p_n = h->d_p_n; p.p_x = h->d_p_x; p.p_y = h->d_p_y; p.p_xv = h->d_p_xv; p.p_yv = h->d_p_yv;
   p.p_scale = h->d_p_scale; p.p_ca = h->d_p_ca; p.p_sa = h->d_p_sa; p.p_shape = h->d_p_shape; p.p_rgb = h->d_p_rgb;
   p.p_label = h->d_p_label; p.pool_base = h->d_pool_base; p.pool_len = h->d_pool_len;
+  p.p_cell_label = h->keyed ? h->d_p_cell_label : nullptr;
   h->pool_entries = P;
   h->pool_sampled = false;
   // polygon vertices of the largest episode: sizes the per-wave edge records and centred paths in LDS
@@ -768,6 +786,8 @@ int swb_sample_pool(swb_handle h, const swb_sampler* spec, int32_t n_entries, co
   HIP_TRY(hipSetDevice(h->device));
   const int P = n_entries, S = h->p.S, T = h->p.n_tasks, N = h->p.N;
   if (P < 1) return fail(SWB_ERR_INVALID, "pool is empty");
+  if (h->keyed) return fail(SWB_ERR_INVALID, "a task of this handle keys on position: its labels depend on where a sprite is drawn -- sample such "
+                            "generators on the host (swb_set_pool with swb_pool::cell_label)");
   if (spec->n_groups < 1 || spec->n_groups > SWB_MAX_GROUPS) return fail(SWB_ERR_INVALID, "n_groups must be in [1, %d]", SWB_MAX_GROUPS);
   if (spec->shuffle < 0) return fail(SWB_ERR_INVALID, "shuffle must be >= 0");
   if (spec->n_alternatives < 0 || spec->n_alternatives > SWB_MAX_ALTERNATIVES)
@@ -1102,11 +1122,13 @@ int ov_allocate(swb_engine* h) {
   rc |= upload<double>(&h->d_ov_angle, nullptr, NS);
   rc |= upload<int8_t>(&h->d_ov_label, nullptr, NS * T);
   rc |= upload<double>(&h->d_ov_cpath, nullptr, NS * SWB_MAX_SHAPE_VERTS * 2);
+  if (h->keyed) rc |= upload<int8_t>(&h->d_ov_cell_label, nullptr, NS * T * SWB_MAX_CELLS);
   rc |= upload<uint8_t>(&h->d_ov_flag, nullptr, N);       // last: its presence switches the engine to the OV kernels
   if (rc) return SWB_ERR_HIP;
   swb_params& p = h->p;
   p.ov_flag = h->d_ov_flag; p.ov_shape = h->d_ov_shape; p.ov_scale = h->d_ov_scale; p.ov_angle = h->d_ov_angle;
   p.ov_label = h->d_ov_label; p.ov_cpath = h->d_ov_cpath;
+  p.ov_cell_label = h->d_ov_cell_label;
   return 0;
 }
 
@@ -1223,8 +1245,29 @@ int swb_set_sprite_attr(swb_handle h, int32_t env, int32_t sprite, int32_t attr,
   for (int s2 = 0; s2 < n; ++s2) tot += h->shape_nverts[r.shape[s2]];
   h->p.max_edges = std::max(h->p.max_edges, (tot + 3) & ~3);
   if (int rc = ov_allocate(h)) return rc;
-  (void)was_set;
+  if (!was_set && h->keyed) {                          // the episode's per-cell labels: from its pool entry, until
+    int32_t en = 0;                                    // swb_set_sprite_cell_labels replaces the sprite's
+    HIP_TRY(hipMemcpy(&en, h->d_entry + env, 4, hipMemcpyDeviceToHost));
+    const size_t blk = (size_t)T * S * SWB_MAX_CELLS;
+    HIP_TRY(hipMemcpy(h->d_ov_cell_label + (size_t)env * blk, h->d_p_cell_label + (size_t)en * blk, blk, hipMemcpyDeviceToDevice));
+  }
   return ov_store(h, env, r);
+}
+
+int swb_set_sprite_cell_labels(swb_handle h, int32_t env, int32_t sprite, const int8_t* cells, void* stream) {
+  if (!h || !cells) return fail(SWB_ERR_INVALID, "null argument");
+  if (!h->keyed) return fail(SWB_ERR_INVALID, "no task of this handle keys on position");
+  if (env < 0 || env >= h->p.N || sprite < 0 || sprite >= h->p.S) return fail(SWB_ERR_INVALID, "environment %d / sprite %d out of range", env, sprite);
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  uint8_t flag = 0;
+  if (h->d_ov_flag) HIP_TRY(hipMemcpy(&flag, h->d_ov_flag + env, 1, hipMemcpyDeviceToHost));
+  if (!flag) return fail(SWB_ERR_STATE, "swb_set_sprite_cell_labels follows swb_set_sprite_attr on the same environment");
+  const int S = h->p.S, T = h->p.n_tasks;
+  for (int t = 0; t < T; ++t)
+    HIP_TRY(hipMemcpy(h->d_ov_cell_label + (((size_t)env * T + t) * S + sprite) * SWB_MAX_CELLS, cells + (size_t)t * SWB_MAX_CELLS,
+                      SWB_MAX_CELLS, hipMemcpyHostToDevice));
+  return SWB_OK;
 }
 
 int swb_get_sprite(swb_handle h, int32_t env, int32_t sprite, int32_t* shape, double* angle, double* scale, int32_t* n_verts,

@@ -227,6 +227,11 @@ class DeviceSampler(object):
     for d in range(360):  # sprite.py:147-151 rotates by radians of the stored degrees
       spec.deg_cos[d], spec.deg_sin[d] = math.cos(math.radians(d)), math.sin(math.radians(d))
     subs = subtasks_of(task)
+    for sub in subs:      # labels that depend on WHERE a sprite is drawn (and then moved) are tabulated per episode on the host
+      xc, yc = lowering.position_cuts(sub, True)
+      if xc or yc:
+        raise LoweringError('a task filter keys on position: its episodes are sampled on the host (lowering.lower_episodes '
+                            'tabulates each sprite\'s label over the filter\'s position grid)')
     for g, (dist, lo, hi, marg) in enumerate(self.groups):
       grp = spec.groups[g]
       grp.count_min, grp.count_max = lo, hi

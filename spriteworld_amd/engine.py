@@ -200,12 +200,17 @@ class Engine(object):
     y = np.ascontiguousarray(y, dtype=np.float64)
     _lib.check(self.lib.swb_set_positions(self._h, _ptr(x), _ptr(y), self._stream()))
 
-  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
-    """sprite.py:152-175 setters on a live sprite (swb_set_sprite_attr; attr: _abi.ATTR_SHAPE / ATTR_ANGLE / ATTR_SCALE)."""
+  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None, cell_label=None):
+    """sprite.py:152-175 setters on a live sprite (swb_set_sprite_attr; attr: _abi.ATTR_SHAPE / ATTR_ANGLE / ATTR_SCALE).
+    cell_label: i8[n_tasks, SWB_MAX_CELLS], the sprite's labels per cell for tasks that key on position."""
     d = None if delta is None else C.byref(C.c_double(float(delta)))
     lab = None if label is None else np.ascontiguousarray(label, dtype=np.int8)
     _lib.check(self.lib.swb_set_sprite_attr(self._h, int(env), int(sprite), int(attr), float(value), d, _ptr(lab),
                                             self._stream()))
+    if cell_label is not None:
+      cells = np.ascontiguousarray(cell_label, dtype=np.int8)
+      assert cells.shape == (self.cfg.n_tasks, _abi.SWB_MAX_CELLS), cells.shape
+      _lib.check(self.lib.swb_set_sprite_cell_labels(self._h, int(env), int(sprite), _ptr(cells), self._stream()))
 
   def get_sprite(self, env, sprite):
     """dict(shape=index, angle, scale, path=f64[n,2]): the sprite as the engine currently sees it (swb_get_sprite)."""

@@ -301,7 +301,17 @@ class BatchedEnvironment(object):
     before = factors[name]               # (one read of the sprite serves the labels and the setter's difference)
     factors[name] = value
     proxy = collections.namedtuple('_Factors', ['factors'])(factors)
-    label = np.array([lowering._label_of(sub, proxy) for sub in lowering.subtasks_of(self._task)], dtype=np.int8)  # pylint: disable=protected-access
+    subs = lowering.subtasks_of(self._task)
+    label = np.array([lowering._label_of(sub, proxy) for sub in subs], dtype=np.int8)  # pylint: disable=protected-access
+    # tasks whose filters key on position: the sprite's label in every cell of the task's grid, with the new attribute
+    cell_label = None
+    f32 = bool(self._cfg.pos_is_f32)
+    cuts = [lowering.position_cuts(sub, f32) for sub in subs]
+    if any(xc or yc for xc, yc in cuts):
+      cell_label = np.zeros((len(subs), _abi.SWB_MAX_CELLS), np.int8)
+      for t, (sub, (xc, yc)) in enumerate(zip(subs, cuts)):
+        if xc or yc:
+          cell_label[t] = lowering.cell_labels_of(sub, proxy, xc, yc, np.float32 if f32 else np.float64)
     delta = None
     episode = self._engine.env_state(env)['episode']
     if name != 'shape':
@@ -311,7 +321,7 @@ class BatchedEnvironment(object):
       old = np.float32(old) if self._attr_is_f32(env, sprite, name, episode, old) else float(old)
       delta = float(value - old)
     self._engine.set_sprite_attr(env, sprite, attr, shapes_lib.shape_index(value) if name == 'shape' else float(value),
-                                 delta=delta, label=label)
+                                 delta=delta, label=label, cell_label=cell_label)
     if name != 'shape':           # from now on the attribute is the object the caller assigned
       self._attr_assigned[(env, sprite, name)] = (episode, getattr(value, 'dtype', None) == np.float32)
 

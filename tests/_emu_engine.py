@@ -45,6 +45,7 @@ def lib():
     l.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     if hasattr(l, 'swb_trim_run_lists') or not os.environ.get('SWB_EMU_CSRC'):
       l.swb_trim_run_lists.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+      l.swb_set_sprite_cell_labels.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     l.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
     l.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     l.swb_set_sprite_attr.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -203,10 +204,13 @@ class EmuEngine(object):
     y = np.ascontiguousarray(y, dtype=np.float64)
     check(self.lib.swb_set_positions(self._h, _ptr(x), _ptr(y), None))
 
-  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
+  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None, cell_label=None):
     d = None if delta is None else C.byref(C.c_double(float(delta)))
     lab = None if label is None else np.ascontiguousarray(label, dtype=np.int8)
     check(self.lib.swb_set_sprite_attr(self._h, int(env), int(sprite), int(attr), float(value), d, _ptr(lab), None))
+    if cell_label is not None:
+      cells = np.ascontiguousarray(cell_label, dtype=np.int8)
+      check(self.lib.swb_set_sprite_cell_labels(self._h, int(env), int(sprite), _ptr(cells), None))
 
   def get_sprite(self, env, sprite):
     shape, nv = C.c_int32(0), C.c_int32(0)

@@ -73,9 +73,9 @@ class FakeEngine(object):
   def set_positions(self, x, y):
     self._ora.set_positions(x, y)
 
-  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None):
+  def set_sprite_attr(self, env, sprite, attr, value, delta=None, label=None, cell_label=None):
     try:
-      self._ora.set_sprite_attr(env, sprite, attr, value, delta=delta, label=label)
+      self._ora.set_sprite_attr(env, sprite, attr, value, delta=delta, label=label, cell_label=cell_label)
     except ValueError as e:
       raise FakeEngineError(str(e))
 

@@ -151,3 +151,49 @@ def live_sprite_case():
   ts = env.step(env.null_actions())
   assert ts.step_type.cpu().numpy().tolist() == [2, 1, 2, 2]
   env.close()
+
+
+def setter_under_a_position_filter_case():
+  """Round 6: a filter keyed on an attribute AND on position -- Product([Discrete('shape', ['circle']), Continuous('x', 0, 0.5)]).
+  A setter re-labels the sprite in every cell of the filter's position grid (swb_set_sprite_cell_labels), and where the sprite
+  stands decides, step by step, whether it counts: the reference's `contains(sprite.factors)` at every step
+  (tasks.py:134-137).  The sprite that becomes a circle is a target while it is in the left half, and stops being one when it is
+  dragged to the right."""
+  from spriteworld_amd import action_spaces, environment, renderers, sprite_generators, tasks
+  from spriteworld_amd import factor_distributions as distribs
+  np.random.seed(6)
+  left = distribs.Product([
+      distribs.Continuous('x', 0.1, 0.4), distribs.Continuous('y', 0.3, 0.7), distribs.Discrete('shape', ['square']),
+      distribs.Discrete('scale', [0.2]), distribs.Continuous('c0', 0., 1.), distribs.Continuous('c1', 0.5, 1.),
+      distribs.Continuous('c2', 0.9, 1.)])
+  env = environment.BatchedEnvironment(
+      task=tasks.FindGoalPosition(filter_distrib=distribs.Product([distribs.Discrete('shape', ['circle']), distribs.Continuous('x', 0., 0.5)]),
+                                  goal_position=(3., 3.), terminate_distance=0.01),
+      action_space=action_spaces.DragAndDrop(scale=1.0),
+      renderers={'image': renderers.PILRenderer(image_size=(32, 32), anti_aliasing=2, color_to_rgb=renderers.hsv_to_rgb)},
+      init_sprites=sprite_generators.generate_sprites(left, num_sprites=1), max_episode_length=50, num_envs=3, device_reset='auto')
+  env.reset()
+  # no circle anywhere: no sprite passes the filter, the (vacuous) success ends every episode -- except where one becomes a circle
+  env.sprites(1)[0].shape = 'circle'
+  ts = env.step(env.null_actions())
+  assert ts.step_type.cpu().numpy().tolist() == [2, 1, 2]          # environment 1 has a target now (far from the goal)
+  assert np.isnan(ts.reward.cpu().numpy()[[0, 2]]).all() and not np.isnan(ts.reward.cpu().numpy()[1])
+  # drag that circle into the right half: it is a circle still, but no longer in the filter's x range -> no target, NaN reward,
+  # vacuous success, the episode ends
+  st = env.state()
+  x, y = float(st['x'][1, 0]), float(st['y'][1, 0])
+  act = env.null_actions()
+  act[1] = torch_row(act, [x, y, min(x + 0.45, 1.0), y])
+  env.step(env.null_actions())                                      # (environments 0 and 2 reset; 1 goes on)
+  env.sprites(0)[0].shape = 'circle'                                # a circle in environment 0 as well, staying left
+  ts = env.step(act)
+  r = ts.reward.cpu().numpy()
+  assert env.state()['x'][1, 0] >= 0.5
+  assert np.isnan(r[1]) and ts.step_type.cpu().numpy()[1] == 2      # moved out of the filter: no target any more
+  assert not np.isnan(r[0]) and ts.step_type.cpu().numpy()[0] == 1  # still a target on the left
+  env.close()
+
+
+def torch_row(like, values):
+  import torch
+  return torch.as_tensor(values, dtype=like.dtype, device=like.device)

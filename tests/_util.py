@@ -45,6 +45,8 @@ def load_golden(name):
   pool = lowering.Pool(P, cfg.max_sprites, cfg.n_tasks)
   for f in lowering.Pool.FIELDS:
     setattr(pool, f, np.ascontiguousarray(z['pool_' + f]))
+  if 'pool_cell_label' in z.files:        # tasks whose filters key on position (round 6)
+    pool.cell_label = np.ascontiguousarray(z['pool_cell_label'])
   return cfg, pool, z
 
 

@@ -53,6 +53,10 @@ CASES = [
     ('examples_embodied_test', 'spriteworld.configs.examples.goal_finding_embodied', 'test', 8, 120, 27),
     ('examples_goal_clustering_test', 'spriteworld.configs.examples.goal_finding_clustering', 'test', 8, 120, 28),
 ]
+# round 6: tasks whose filters key on position (tests/_position_cases.py, built from the reference's own classes): name, float32 positions
+POSITION_CASES = [(c, f32) for c in ('goal_x_lt_half', 'goal_two_xbands', 'goal_all_but_a_corner', 'goal_whole_frame_half_open',
+                                     'goal_f64_bounds', 'meta_swap_sides') for f32 in (True, False)
+                  if (c, f32) not in (('goal_two_xbands', False), ('goal_all_but_a_corner', True), ('goal_f64_bounds', False))]
 FULL_FRAMES = 6
 
 
@@ -65,16 +69,25 @@ def versions():
       ' '.join(platform.libc_ver()), platform.python_version())
 
 
-def make(name, module, mode, n_eps, n_steps, seed, action_dtype='float64', motion_cost=None):
+def make(name, module, mode, n_eps, n_steps, seed, action_dtype='float64', motion_cost=None, position_case=None):
   from spriteworld import action_spaces, environment
   from spriteworld import renderers as ref_renderers
-  mod = importlib.import_module(module)
   np.random.seed(seed)
-  config = mod.get_config(mode)
-  if motion_cost is not None:
-    config['action_space'] = action_spaces.SelectMove(scale=0.25, motion_cost=motion_cost)
-  gen = config['init_sprites']
-  episodes = [gen() for _ in range(n_eps)]
+  if position_case is not None:
+    from tests import _position_cases as pc
+    case, f32 = position_case
+    ns = pc.namespace_of_reference()
+    task, aspace, rends, keep, max_len = pc.environment_parts(ns, case)
+    config = dict(task=task, action_space=aspace, renderers=rends, keep_in_frame=keep, max_episode_length=max_len)
+    episodes = pc.episodes_of(ns, case, f32, n_episodes=n_eps, seed=seed)
+    module, mode = 'tests/_position_cases.py:%s' % case, 'f32' if f32 else 'f64'
+  else:
+    mod = importlib.import_module(module)
+    config = mod.get_config(mode)
+    if motion_cost is not None:
+      config['action_space'] = action_spaces.SelectMove(scale=0.25, motion_cost=motion_cost)
+    gen = config['init_sprites']
+    episodes = [gen() for _ in range(n_eps)]
   task, aspace, rends = config['task'], config['action_space'], config['renderers']
   S = max(len(e) for e in episodes)
   pos_dt = lowering.position_dtype(episodes)
@@ -107,6 +120,8 @@ def make(name, module, mode, n_eps, n_steps, seed, action_dtype='float64', motio
       ts = env.step([int(a[0]), int(a[1])])
     else:
       a = rng.uniform(0, 1, 4).astype(action_dtype)
+      if position_case is not None and t % 3 == 0 and env._sprites:     # click ON a sprite: something moves most steps
+        a[:2] = np.asarray(env._sprites[rng.randint(len(env._sprites))].position, dtype=np.float64)
       ts = env.step(a)
     actions[t] = a
     out['step_type'][t] = int(ts.step_type)
@@ -126,6 +141,8 @@ def make(name, module, mode, n_eps, n_steps, seed, action_dtype='float64', motio
           'source': np.array('%s mode=%s seed=%d' % (module, mode, seed))}
   for f in lowering.Pool.FIELDS:
     save['pool_' + f] = getattr(pool, f)
+  if pool.cell_label is not None:
+    save['pool_cell_label'] = pool.cell_label
   for k, v in out.items():
     save['ref_' + k] = v
   np.savez_compressed(os.path.join(HERE, name + '.npz'), **save)
@@ -139,6 +156,10 @@ def main():
   for case in CASES:
     if not only or case[0] in only:
       make(*case)
+  for k, (case, f32) in enumerate(POSITION_CASES):
+    name = 'position_%s_%s' % (case, 'f32' if f32 else 'f64')
+    if not only or name in only:
+      make(name, None, None, 10, 150, 40 + k, position_case=(case, f32))
   # shape tables
   from spriteworld import constants
   import json

@@ -513,3 +513,48 @@ def test_emulated_gym_wrapper_and_single_environment(monkeypatch):
     G.test_reference_gym_wrapper_episode_pattern(embodied)
   H.test_single_environment_follows_example_run_loop()
   H.test_sprite_factors_observation_and_action_noise()
+
+
+@pytest.mark.parametrize('f32', [True, False], ids=['f32pos', 'f64pos'])
+@pytest.mark.parametrize('name', __import__('tests._position_cases', fromlist=['CASES']).CASES)
+def test_emulated_kernel_tasks_that_filter_on_position(name, f32):
+  """Round 6: task filters / cluster distributions keyed on x, y (tests/_position_cases.py; pinned against the unmodified
+  reference through the oracle in tests/test_oracle_vs_reference.py and through tests/golden/position_*.npz).  The kernel looks
+  every sprite's label up in the cell of the task's position grid it stands in, every step."""
+  from oracle import oracle
+  from spriteworld_amd import lowering
+  from tests import _position_cases as pc
+  ns = pc.namespace_of_mirrors()
+  task, aspace, rends, keep, max_len = pc.environment_parts(ns, name)
+  n_envs = 5
+  episodes = pc.episodes_of(ns, name, f32, n_episodes=3 * n_envs)
+  cfg = lowering.lower_config(task, aspace, rends, keep, max_len, n_envs, pc.N_SPRITES, pos_is_f32=f32)
+  pool = lowering.lower_episodes(episodes, task, rends, max_sprites=pc.N_SPRITES).assign_round_robin(n_envs, 3)
+  assert pool.cell_label is not None
+  ora, eng = oracle.Engine(cfg, pool), _emu(cfg, pool)
+  rng = np.random.default_rng(11)
+  flips = 0
+  prev = None
+  sticky = np.zeros(n_envs, np.uint8)
+  for t in range(40):
+    a = rng.uniform(0.0, 1.0, size=(n_envs, 4))
+    st = ora.state()
+    for i in range(0, n_envs, 2):                      # click ON a sprite in every second environment
+      k = int(rng.integers(0, max(int(st['n_sprites'][i]), 1)))
+      a[i, 0], a[i, 1] = st['x'][i, k], st['y'][i, k]
+    want = ora.step(a)
+    eng.step(a)
+    got = eng.outputs_host()
+    np.testing.assert_array_equal(got['step_type'], want['step_type'])
+    np.testing.assert_array_equal(got['success'], want['success'])
+    assert np.array_equal(np.isnan(got['reward']), np.isnan(want['reward']))
+    ok = ~np.isnan(want['reward'])
+    np.testing.assert_array_equal(_bits(got['reward'][ok]), _bits(want['reward'][ok]))
+    sticky |= want['error']                            # (the engine's error flags are sticky; the oracle's are per step)
+    np.testing.assert_array_equal(got['error'], sticky)
+    np.testing.assert_array_equal(got['obs'], want['obs'])
+    if prev is not None:
+      flips += int((want['reward'] != prev).sum())
+    prev = want['reward']
+  assert flips > 20
+  eng.close()

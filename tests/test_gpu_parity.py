@@ -287,3 +287,48 @@ def test_fill_kernel_for_narrow_images(monkeypatch, name, n_envs):
   through the run lists and the fill kernel, the path wider images always take (test_image_geometries covers those)."""
   monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')
   _run(name, n_envs, 3, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('f32', [True, False], ids=['f32pos', 'f64pos'])
+@pytest.mark.parametrize('name', __import__('tests._position_cases', fromlist=['CASES']).CASES)
+def test_tasks_that_filter_on_position(name, f32):
+  """Round 6: task filters / cluster distributions keyed on x, y -- the reference re-evaluates `contains(sprite.factors)` at
+  every step (tasks.py:134-137, 196-205); the kernel looks every sprite's label up in the cell of the task's position grid it
+  stands in.  HIP engine against the oracle (which tests/test_oracle_vs_reference.py pins against the unmodified reference on
+  these very cases; tests/golden/position_*.npz are the reference's own outputs, checked in tests/test_golden.py)."""
+  from oracle import oracle
+  from spriteworld_amd import engine, lowering
+  from tests import _position_cases as pc
+  ns = pc.namespace_of_mirrors()
+  task, aspace, rends, keep, max_len = pc.environment_parts(ns, name)
+  n_envs = 96
+  episodes = pc.episodes_of(ns, name, f32, n_episodes=3 * n_envs)
+  cfg = lowering.lower_config(task, aspace, rends, keep, max_len, n_envs, pc.N_SPRITES, pos_is_f32=f32)
+  pool = lowering.lower_episodes(episodes, task, rends, max_sprites=pc.N_SPRITES).assign_round_robin(n_envs, 3)
+  ora, eng = oracle.Engine(cfg, pool), engine.Engine(cfg, pool)
+  rng = np.random.default_rng(11)
+  sticky = np.zeros(n_envs, np.uint8)
+  flips, prev = 0, None
+  for t in range(40):
+    a = rng.uniform(0.0, 1.0, size=(n_envs, 4))
+    st = ora.state()
+    for i in range(0, n_envs, 2):                      # click ON a sprite in every second environment
+      k = int(rng.integers(0, max(int(st['n_sprites'][i]), 1)))
+      a[i, 0], a[i, 1] = st['x'][i, k], st['y'][i, k]
+    want = ora.step(a)
+    eng.step(a)
+    got = eng.outputs_host()
+    np.testing.assert_array_equal(got['step_type'], want['step_type'])
+    np.testing.assert_array_equal(got['success'], want['success'])
+    assert np.array_equal(np.isnan(got['reward']), np.isnan(want['reward']))
+    ok = ~np.isnan(want['reward'])
+    np.testing.assert_array_equal(got['reward'][ok].view(np.uint64), want['reward'][ok].view(np.uint64))
+    sticky |= want['error']
+    np.testing.assert_array_equal(got['error'], sticky)
+    np.testing.assert_array_equal(got['obs'], want['obs'])
+    if prev is not None:
+      flips += int((want['reward'] != prev).sum())
+    prev = want['reward']
+  assert flips > 200
+  eng.close()

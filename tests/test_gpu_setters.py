@@ -43,3 +43,7 @@ def test_factors_observation_and_reset_semantics():
 
 def test_live_sprite_handles_follow_the_reference_setters():
   cases.live_sprite_case()
+
+
+def test_setter_under_a_filter_that_also_keys_on_position():
+  cases.setter_under_a_position_filter_case()

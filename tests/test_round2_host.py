@@ -20,21 +20,44 @@ def _bench():
 
 
 @pytest.mark.parametrize('key', ['x', 'y'])
-def test_filters_on_moving_factors_are_refused(key):
-  """tasks.py:134-137,196-204 evaluate contains(sprite.factors) every step; the pool label is per episode, so
-  a filter / cluster distribution that keys on x or y cannot be lowered."""
+def test_filters_on_moving_factors_lower_to_position_cuts(key):
+  """tasks.py:134-137,196-204 evaluate contains(sprite.factors) every step.  Until round 5 a filter / cluster distribution that
+  keys on x or y was refused; now its interval bounds become the task's position cuts (swb_task::xcuts / ycuts) and the pool
+  tabulates every sprite's label per cell.  What still cannot be lowered says so: more than SWB_MAX_CUTS bounds on an axis,
+  membership by EQUALITY with a position (Discrete), and sampling such a task's episodes on the device."""
   rend = {'image': renderers.PILRenderer(image_size=(64, 64))}
   moving = distribs.Continuous(key, 0., 0.5)
-  with pytest.raises(lowering.LoweringError):
-    lowering.lower_config(tasks.FindGoalPosition(filter_distrib=moving), action_spaces.SelectMove(), rend)
-  with pytest.raises(lowering.LoweringError):
-    lowering.lower_config(tasks.Clustering([moving, distribs.Continuous('c0', 0., 0.5)]), action_spaces.SelectMove(), rend)
+  cfg = lowering.lower_config(tasks.FindGoalPosition(filter_distrib=moving), action_spaces.SelectMove(), rend)
+  t = cfg.tasks[0]
+  n, cuts = (t.n_xcuts, t.xcuts) if key == 'x' else (t.n_ycuts, t.ycuts)
+  assert (n, cuts[0], cuts[1]) == (2, 0.0, 0.5) and t.n_xcuts + t.n_ycuts == 2
+  cfg = lowering.lower_config(tasks.Clustering([moving, distribs.Continuous('c0', 0., 0.5)]), action_spaces.SelectMove(), rend)
+  assert cfg.tasks[0].n_xcuts + cfg.tasks[0].n_ycuts == 2
   meta = tasks.MetaAggregated([tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.5)),
                                tasks.FindGoalPosition(filter_distrib=moving)])
-  with pytest.raises(lowering.LoweringError):
-    lowering.lower_config(meta, action_spaces.SelectMove(), rend)
-  # static keys are fine
-  lowering.lower_config(tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.5)), action_spaces.SelectMove(), rend)
+  cfg = lowering.lower_config(meta, action_spaces.SelectMove(), rend)
+  assert cfg.tasks[0].n_xcuts + cfg.tasks[0].n_ycuts == 0 and cfg.tasks[1].n_xcuts + cfg.tasks[1].n_ycuts == 2
+  # float32 positions compare with the bound rounded to float32 (NEP 50); float64 positions with the bound itself
+  cfg32 = lowering.lower_config(tasks.FindGoalPosition(filter_distrib=distribs.Continuous(key, 0.1, 0.7)), action_spaces.SelectMove(), rend,
+                                pos_is_f32=True)
+  cfg64 = lowering.lower_config(tasks.FindGoalPosition(filter_distrib=distribs.Continuous(key, 0.1, 0.7)), action_spaces.SelectMove(), rend,
+                                pos_is_f32=False)
+  c32 = cfg32.tasks[0].xcuts if key == 'x' else cfg32.tasks[0].ycuts
+  c64 = cfg64.tasks[0].xcuts if key == 'x' else cfg64.tasks[0].ycuts
+  assert (c32[0], c32[1]) == (float(np.float32(0.1)), float(np.float32(0.7))) and (c64[0], c64[1]) == (0.1, 0.7)
+  # static keys: no cuts
+  cfg = lowering.lower_config(tasks.FindGoalPosition(filter_distrib=distribs.Continuous('c0', 0., 0.5)), action_spaces.SelectMove(), rend)
+  assert cfg.tasks[0].n_xcuts + cfg.tasks[0].n_ycuts == 0
+  with pytest.raises(lowering.LoweringError):      # six bounds on one axis
+    many = distribs.Mixture([distribs.Continuous(key, 0.1 * k, 0.1 * k + 0.05) for k in range(3)])
+    lowering.lower_config(tasks.FindGoalPosition(filter_distrib=many), action_spaces.SelectMove(), rend)
+  with pytest.raises(lowering.LoweringError):      # equality with a position
+    lowering.lower_config(tasks.FindGoalPosition(filter_distrib=distribs.Discrete(key, [0.5])), action_spaces.SelectMove(), rend)
+  factors = distribs.Product([distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9), distribs.Discrete('shape', ['square']),
+                              distribs.Discrete('scale', [0.13]), distribs.Continuous('c0', 0.0, 0.4), distribs.Continuous('c1', 0.3, 1.),
+                              distribs.Continuous('c2', 0.9, 1.)])
+  with pytest.raises(lowering.LoweringError):      # episodes of such a task are drawn on the host
+    device_sampler.DeviceSampler([(factors, 3)]).lower(tasks.FindGoalPosition(filter_distrib=moving), rend)
 
 
 def test_label_probes_leave_the_global_numpy_stream_alone():

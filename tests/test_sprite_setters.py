@@ -183,6 +183,14 @@ def test_live_sprite_api_on_the_fake_engine(monkeypatch):
   _setter_cases.live_sprite_case()
 
 
+@pytest.mark.parametrize('backend', ['fake', 'emu'])
+def test_setter_under_a_filter_that_also_keys_on_position(monkeypatch, backend):
+  from spriteworld_amd import environment
+  from tests import _emu_engine, _fake_engine, _setter_cases
+  monkeypatch.setattr(environment._engine, 'Engine', _fake_engine.FakeEngine if backend == 'fake' else _emu_engine.EmuTorchEngine)
+  _setter_cases.setter_under_a_position_filter_case()
+
+
 @needs_reference
 def test_setters_on_float32_attributes_equal_the_reference_sprite(monkeypatch):
   """factor distributions give sprites np.float32 scales; the reference's setter then takes `s - self._scale`
