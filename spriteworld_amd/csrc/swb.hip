@@ -102,6 +102,7 @@ struct swb_engine {
   int launch_parity = 0;
   // hand-off cover -> resample
   uint32_t *d_runs = nullptr, *d_rhdr = nullptr, *d_arena_head = nullptr;
+  int32_t* d_env_state = nullptr;    // swb_get_env_state's 20-byte record
   int arena_override = -1;           // SWB_ARENA_UNITS (tests): units of the shared arena; -1: sized from the batch
   int run_cap_worst = 0;             // (max(4, S + 1) canvas heights + 1: what a list reserves until swb_trim_run_lists)
   bool lists_trimmed = false;        // the lists have been cut down to what the launches so far needed
@@ -589,7 +590,7 @@ int swb_destroy(swb_handle h) {
                   h->d_p_shape, h->d_p_rgb, h->d_p_label, h->d_p_cell_label, h->d_ov_cell_label, h->d_p_attr, h->d_pool_base, h->d_pool_len, h->d_x, h->d_y, h->d_nspr,
                   h->d_entry, h->d_step_count, h->d_episode, h->d_reset_next, h->d_ovf, h->d_ovf_bitmap, h->d_p_angle, h->d_p_color, h->d_sampler,
                   h->d_ov_flag, h->d_ov_shape, h->d_ov_scale, h->d_ov_angle, h->d_ov_cpath, h->d_ov_label,
-                  h->d_cost_cnt, h->d_cost_list, h->d_ccost_list, h->d_runs, h->d_rhdr, h->d_arena_head, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
+                  h->d_cost_cnt, h->d_cost_list, h->d_ccost_list, h->d_runs, h->d_rhdr, h->d_arena_head, h->d_env_state, h->d_band_y0, h->d_band_first, h->d_band_lo, h->d_cg_lo, h->d_cg_hi, h->d_v_break};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete h;
   return SWB_OK;
@@ -1031,14 +1032,13 @@ int swb_get_env_state(swb_handle h, int32_t env, int32_t* out5, void* stream) {
   if (!h || !out5) return fail(SWB_ERR_INVALID, "null argument");
   if (env < 0 || env >= h->p.N) return fail(SWB_ERR_INVALID, "environment %d out of range", env);
   HIP_TRY(hipSetDevice(h->device));
+  // (the N = 1 drop-in asks for this several times per step: one gather kernel and ONE 20-byte copy, stream-ordered behind
+  // the steps, instead of a stream synchronisation and five 4-byte copies)
+  if (!h->d_env_state && upload(&h->d_env_state, (const int32_t*)nullptr, 8)) return SWB_ERR_HIP;
+  hipLaunchKernelGGL(swb_env_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->p, env, h->d_env_state);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out5, h->d_env_state, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  uint8_t rn = 0;
-  HIP_TRY(hipMemcpy(&out5[0], h->d_nspr + env, 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(&out5[1], h->d_entry + env, 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(&out5[2], h->d_step_count + env, 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(&out5[3], h->d_episode + env, 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(&rn, h->d_reset_next + env, 1, hipMemcpyDeviceToHost));
-  out5[4] = rn;
   return SWB_OK;
 }
 

@@ -266,11 +266,17 @@ class BatchedEnvironment(object):
     return self._timestep()
 
   def observation(self):
+    """environment.py:136-142: every renderer's view of the sprites AS THEY ARE NOW -- the frame is rendered now (swb_render)
+    and a Success renderer evaluates the task now (swb_evaluate; environment.py:128-131 `state()` calls `success()` on the
+    current sprites), so that a setter or `set_positions` since the last step shows in both (round-5 advice: the Success key
+    used to carry the last step's flag)."""
     obs = {}
     if self._image_key is not None:
       obs[self._image_key] = self._engine.render()
-    for k in self._success_keys:
-      obs[k] = self._engine.success.bool()
+    if self._success_keys:
+      success = self._engine.evaluate().bool()
+      for k in self._success_keys:
+        obs[k] = success
     self._add_factor_obs(obs)
     return obs
 
