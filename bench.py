@@ -93,20 +93,37 @@ class TimedRun(object):
   durations of the two kernels apart come from a short pass in that mode AFTER the timed region (`split`): each carries the
   cost of its own completion event, as it does under rocprofv3's kernel trace, so their sum exceeds `kernel_ms`."""
 
-  def __init__(self, name, n_envs, steps, warmup, aa, device, seed=0, verify=0):
+  def __init__(self, name, n_envs, steps, warmup, aa, device, seed=0, verify=0, protocol_8d=None):
+    """protocol_8d: None, or (index of this run's first environment in the job, environments of the whole job)."""
     self.name, self.n_envs, self.steps, self.warmup, self.aa, self.device = name, n_envs, steps, warmup, aa, device
-    self.seed, self.verify = seed, verify
+    self.seed, self.verify, self.protocol_8d = seed, verify, protocol_8d
     self.run_error, self.elapsed = None, None
 
-  def build(self):
+  def build(self, inputs=None):
+    """`inputs`: (cfg, pool, action sets) of another run of the same workload to share (the clock-ramp twin)."""
     import torch
     from spriteworld_amd import engine, workloads
-    self.cfg, self.pool, sample = workloads.build(self.name, self.n_envs, episodes_per_env=4, seed=self.seed, anti_aliasing=self.aa)
+    if inputs is not None:
+      self.cfg, self.pool, self.acts_host, self.data = inputs
+    elif self.protocol_8d:
+      # SURVEY 8d, literally: every environment's pool from the reference's own generators under np.random.seed(1000 + env),
+      # the actions of step t from RandomState(2000 + t) -- N_ACTION_SETS of them, cycled
+      self.cfg, self.pool, actions_of_step = workloads.build_protocol_8d(self.name, self.n_envs, 4, self.aa,
+                                                                       env_offset=self.protocol_8d[0], total_envs=self.protocol_8d[1])
+      self.acts_host = [actions_of_step(t) for t in range(N_ACTION_SETS)]
+      self.data = ('synthetic, SURVEY 8d protocol: reset pools drawn by the reference\'s generators (this package\'s mirrors: the same '
+                   'draws) under np.random.seed(1000 + env), actions RandomState(2000 + (step mod %d)).uniform' % N_ACTION_SETS)
+    else:
+      self.cfg, self.pool, sample = workloads.build(self.name, self.n_envs, episodes_per_env=4, seed=self.seed, anti_aliasing=self.aa)
+      rng = np.random.default_rng(2000 + self.seed)
+      self.acts_host = [sample(rng) for _ in range(N_ACTION_SETS)]
+      self.data = 'synthetic'
     self.eng = engine.Engine(self.cfg, self.pool, device=self.device)
-    rng = np.random.default_rng(2000 + self.seed)
-    self.acts_host = [sample(rng) for _ in range(N_ACTION_SETS)]
     self.acts = [torch.as_tensor(a, device=self.eng.device) for a in self.acts_host]
     return self
+
+  def inputs(self):
+    return self.cfg, self.pool, self.acts_host, self.data
 
   def go(self, barrier=None, gate=None):
     """`gate` (N > 1): called after the warm-up, returns False when another rank failed to set up -- then nothing is timed
@@ -199,15 +216,16 @@ class TimedRun(object):
     except Exception as e:  # pylint: disable=broad-except
       return dict(error=repr(e), elapsed=elapsed, kernel_ms=0.0, cover_ms=0.0, resample_ms=0.0, launches=0, errors=-1)
     return dict(elapsed=elapsed, kernel_ms=kernel_ms, cover_ms=cover_ms, resample_ms=resample_ms, launches=launches,
-                a_bytes=a_bytes, errors=errors, variant=variant, facts=facts, sample=sample_out, error=None, split=split)
+                a_bytes=a_bytes, errors=errors, variant=variant, facts=facts, sample=sample_out, error=None, split=split,
+                data=getattr(self, 'data', 'synthetic'))
 
 
-def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None, verify=0, before=None):
-  """One timed run, start to end.  `before`: called once the engine and its action sets are on the device, before the first
-  warm-up step (the `extra` runs of the default line: see main()).  Returns None when the gate closed."""
-  run = TimedRun(name, n_envs, steps, warmup, aa, device, seed=seed, verify=verify).build()
+def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None, verify=0, before=None, protocol_8d=None):
+  """One timed run, start to end.  `before(run)`: called once the engine and its action sets are on the device, before the
+  first warm-up step (the clock ramp: see main()).  Returns None when the gate closed."""
+  run = TimedRun(name, n_envs, steps, warmup, aa, device, seed=seed, verify=verify, protocol_8d=protocol_8d).build()
   if before is not None:
-    before()
+    before(run)
   if not run.go(barrier=barrier, gate=gate):
     return None
   return run.finish()
@@ -361,10 +379,12 @@ def port_cpu_baseline(name, aa, budget_s=6.0):
               (n_envs, steps, name, aa, cores, dt))
 
 
-def reference_cpu_baseline(envs_per_core=8, steps=300, warmup=20, timeout_s=240):
+def reference_cpu_baseline(envs_per_core=4, steps=2000, warmup=100, timeout_s=300):
   """The UNMODIFIED reference on every usable core of THIS host, in this run: tools/reference_cpu_baseline.py as a child
   process (a fresh interpreter -- nothing forks beside the HIP context), one worker process per core, each stepping
-  `envs_per_core` reference Environments of the headline scene (BASELINE configs[2]) for `warmup` + `steps` steps.
+  `envs_per_core` reference Environments of the headline scene (BASELINE configs[2]) for `warmup` + `steps` steps -- SURVEY 8d's
+  protocol: the reference's own generators under np.random.seed(1000 + env), actions RandomState(2000 + step), 2000 timed steps
+  after 100 warm-up steps (about 15 s on 16 cores).
   Returns (block, None) or (None, reason)."""
   from oracle import ref_harness
   if not ref_harness.reference_available():
@@ -496,7 +516,7 @@ def assemble_line(args, res, elapsed):
       'scaling': 'weak',
       'vs_baseline': None,
       'dtype': 'i32 fixed-point raster/resample + f64 state',
-      'data': 'synthetic',
+      'data': res.get('data', 'synthetic'),
       'config': {
           'workload': '%s: %d envs/GPU x %d sprites, %s, %s reward, %s PILRenderer anti_aliasing=%d, auto-reset from '
                       'an HBM pool%s' % (args.workload, args.envs_per_gpu, facts['sprites'], facts['action_space'],
@@ -523,6 +543,9 @@ def main():
   ap.add_argument('--aa', type=int, default=5)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extra', action='store_true')
+  ap.add_argument('--protocol', choices=['8d', 'synthetic'], default='8d',
+                  help="inputs of the timed run: '8d' = SURVEY 8d literally (reference generators seeded 1000 + env, actions "
+                       "RandomState(2000 + step); rank 0 of cluster_s5 / goal_s5), 'synthetic' = the same distributions drawn with numpy")
   ap.add_argument('--ramp-ms', type=float, default=300.0,
                   help='milliseconds of device load (a twin engine of the same workload) in front of the --warmup steps, on every '
                        'rank at every N; 0: none')
@@ -580,10 +603,11 @@ def main():
   # run AFTER the headline, every engine built first, the first of them behind a ramp of its own.
   ramp_info = {}
 
-  def clock_ramp():
+  def clock_ramp(run):
+    ramp_info['data'] = run.data
     if args.ramp_ms <= 0:
       return
-    twin = TimedRun(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device, seed=rank + 1000).build()
+    twin = TimedRun(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device, seed=rank + 1000).build(run.inputs())
     try:
       twin.go()
       ramp_info['cold_ms_per_step'] = twin.event_ms / max(args.steps, 1)
@@ -666,7 +690,9 @@ def main():
     res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
                   barrier=barrier, seed=rank, gate=gate_once if dist is not None else None,
                   verify=64 if (rank == 0 and not args.no_verify) else 0,
-                  before=clock_ramp)
+                  before=clock_ramp,
+                  protocol_8d=((rank * args.envs_per_gpu, args.gpus * args.envs_per_gpu)
+                               if (args.protocol == '8d' and args.workload in ('cluster_s5', 'goal_s5')) else None))
   except Exception as e:  # pylint: disable=broad-except
     if dist is None:
       raise
@@ -732,12 +758,12 @@ def main():
     out['obs_allgather'] = gather
   out['warmup_effective'] = {
       'timed_engine_warmup_steps': args.warmup,
-      'clock_ramp_ms': args.ramp_ms if ramp_info else 0.0,
+      'clock_ramp_ms': args.ramp_ms if 'cold_ms_per_step' in ramp_info else 0.0,
       'clock_ramp_steps': ramp_info.get('clock_ramp_steps', 0),
       'how': ('a twin engine of the same workload timed W + K steps cold, then kept the device busy for clock_ramp_ms, before the '
-              "timed engine's own W warm-up steps; identical on every rank at every N") if ramp_info else 'none (--ramp-ms 0)',
+              "timed engine's own W warm-up steps; identical on every rank at every N") if 'cold_ms_per_step' in ramp_info else 'none (--ramp-ms 0)',
   }
-  if ramp_info:
+  if 'cold_ms_per_step' in ramp_info:
     cold_s = ramp_info['cold_ms_per_step'] / 1e3
     out['cold'] = {'value': args.envs_per_gpu * args.gpus / cold_s if cold_s > 0 else None, 'unit': 'env-steps/s',
                    'ms_per_step': ramp_info['cold_ms_per_step'], 'wall_ms_per_step': ramp_info['cold_wall_ms_per_step'],

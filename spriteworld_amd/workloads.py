@@ -256,3 +256,51 @@ def build(name, num_envs, episodes_per_env=4, seed=0, anti_aliasing=5):
       a = r.uniform(0.0, 1.0, size=(num_envs, 4))
       return a.astype(np.float32) if cfg.action_is_f32 else a
   return cfg, pool, sample
+
+
+def build_protocol_8d(name, num_envs, episodes_per_env=4, anti_aliasing=5, env_offset=0, total_envs=None):
+  """SURVEY.md section 8d's input protocol, literally, for the scenes of BASELINE configs[1] / configs[2]: every environment's
+  reset pool is drawn by the reference's OWN generators -- this package's mirrors of `sprite_generators` / `factor_distributions`,
+  which consume numpy's global stream draw for draw like the reference's (tests/test_host_api.py) -- under
+  `np.random.seed(1000 + env_index)`; actions of step t are `np.random.RandomState(2000 + t).uniform(size=(N, 4))`.
+  A shard of a larger job passes the index of its first environment and the job's size (`env_offset`, `total_envs`): seeds and
+  action rows are those of the global environment indices.
+  Returns (SwbConfig, Pool, actions_of_step(t) -> f64[N, 4]).  (`build()` draws the same distributions with numpy directly, in
+  a fraction of the time: tests use that.)"""
+  from spriteworld_amd import factor_distributions as distribs
+  from spriteworld_amd import sprite_generators
+  rend = _renderers(64, anti_aliasing)
+  common = [distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9),
+            distribs.Discrete('shape', ['square', 'triangle', 'circle']), distribs.Discrete('scale', [0.13]),
+            distribs.Continuous('c1', 0.3, 1.), distribs.Continuous('c2', 0.9, 1.)]
+  if name == 'cluster_s5':       # configs/cobra/clustering.py:41-46,71-109: 2 'blue' + 3 'green', shuffled
+    clusters = [distribs.Continuous('c0', 0.55, 0.65), distribs.Continuous('c0', 0.27, 0.37)]
+    gens = [sprite_generators.generate_sprites(distribs.Product(common + [c0]), num_sprites=n) for c0, n in zip(clusters, (2, 3))]
+    task = tasks.Clustering(clusters, terminate_bonus=0., reward_range=10.)
+    max_len = 50
+  elif name == 'goal_s5':        # configs/cobra/goal_finding_more_distractors.py:54-96: 2 targets + 3 distractors
+    hues = [distribs.Continuous('c0', 0., 0.4), distribs.Continuous('c0', 0.5, 0.9)]
+    gens = [sprite_generators.generate_sprites(distribs.Product(common + [c0]), num_sprites=n) for c0, n in zip(hues, (2, 3))]
+    task = tasks.FindGoalPosition(filter_distrib=hues[0], terminate_distance=0.075)
+    max_len = 20
+  else:
+    raise ValueError('no section-8d protocol for workload ' + name)
+  gen = sprite_generators.shuffle(sprite_generators.chain_generators(*gens))
+  state = np.random.get_state()                     # (the caller's global stream is left as it was)
+  try:
+    episodes = []
+    for env in range(num_envs):
+      np.random.seed(1000 + env_offset + env)
+      episodes.extend(gen() for _ in range(episodes_per_env))
+  finally:
+    np.random.set_state(state)
+  aspace = action_spaces.SelectMove(scale=0.25)
+  cfg = lowering.lower_config(task, aspace, rend, True, max_len, num_envs, 5, True)
+  pool = lowering.lower_episodes(episodes, task, rend, max_sprites=5)
+  pool.assign_round_robin(num_envs, episodes_per_env)
+
+  total = int(total_envs or (env_offset + num_envs))
+
+  def actions_of_step(t):
+    return np.ascontiguousarray(np.random.RandomState(2000 + int(t)).uniform(size=(total, 4))[env_offset:env_offset + num_envs])
+  return cfg, pool, actions_of_step

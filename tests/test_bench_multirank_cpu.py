@@ -62,6 +62,7 @@ def test_two_ranks_print_one_line_of_the_contracts_shape():
   assert d['warmup_effective']['timed_engine_warmup_steps'] == WARMUP and d['warmup_effective']['clock_ramp_steps'] >= 16
   assert d['cold']['ms_per_step'] > 0
   assert 'extra' not in d and 'cpu_baseline' not in d          # N > 1: neither
+  assert 'np.random.seed(1000 + env)' in d['data']             # SURVEY 8d's input protocol, on every rank (global env indices)
 
 
 def test_a_rank_that_cannot_set_up_gives_one_line_with_rank_errors_and_no_hang():
