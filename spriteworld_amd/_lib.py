@@ -62,6 +62,7 @@ def load():
   lib.swb_factors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
   if hasattr(lib, 'swb_trim_run_lists') or not os.environ.get('SWB_LIBRARY'):
     lib.swb_trim_run_lists.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+  if hasattr(lib, 'swb_set_sprite_cell_labels') or not os.environ.get('SWB_LIBRARY'):
     lib.swb_set_sprite_cell_labels.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
   lib.swb_get_state.argtypes = [C.c_void_p, C.POINTER(_abi.SwbState), C.c_void_p]
   lib.swb_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OVERLAYS = [['phase_cut:3'], ['phase_cut:4'], ['phase_cut:5'], ['phase_cut:1'], ['trace'], ['trace_p2'],
-            ['nofile'], ['trace_p1b'], ['define:SWB_RS_WAVES_PER_BLOCK=8'], ['cover_snake']]
+            ['nofile'], ['pow_memory'], ['bisect_r06:cells,grow'], ['trace_p1b'], ['define:SWB_RS_WAVES_PER_BLOCK=8'], ['cover_snake']]
 
 
 def _overlay_build():
