@@ -131,21 +131,28 @@ def test_hip_engine_equals_reference_on_a_batch_of_reference_environments():
   pool.pool_base = np.arange(N, dtype=np.int32) * EPS
   pool.pool_len = np.full(N, EPS, np.int32)
   eng = engine.Engine(cfg, pool)
+  from spriteworld_amd import _abi
+  dropped = set()        # environments in which the reference raised: compared no further (the others go on to the last step)
   for t in range(STEPS):
     acts = np.random.RandomState(2000 + t).uniform(size=(N, 4))
     eng.step(acts)
     out = eng.outputs_host()
     st = eng.state()
-    assert not out['error'].any(), t
     for i, env in enumerate(envs):
+      if i in dropped:
+        continue
       try:
         ts = env.step(acts[i])
-      except ZeroDivisionError:      # tasks.py:215 1. / 0. (collapsed clusters): the engine flags the environment instead
-        pytest.skip('reference raised ZeroDivisionError at t=%d env=%d' % (t, i))
+      except ZeroDivisionError:      # tasks.py:215 1. / 0. (collapsed clusters): the engine flags exactly that environment
+        assert out['error'][i] & _abi.ENV_ERR_DB_ZERO, (t, i)
+        dropped.add(i)
+        continue
+      assert not out['error'][i], (t, i)
       assert int(ts.step_type) == int(out['step_type'][i]), (t, i)
       r = np.nan if ts.reward is None else float(ts.reward)
       assert (np.isnan(r) and np.isnan(out['reward'][i])) or _bits(r) == _bits(out['reward'][i]), (t, i)
       assert np.array_equal(ts.observation['image'], out['obs'][i]), (t, i)
       pos = np.array([s.position for s in env._sprites], dtype=np.float64).reshape(-1, 2)
       assert np.array_equal(pos[:, 0], st['x'][i, :5]) and np.array_equal(pos[:, 1], st['y'][i, :5]), (t, i)
+  assert len(dropped) < N // 4, sorted(dropped)
   eng.close()
