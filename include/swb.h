@@ -401,8 +401,7 @@ typedef struct swb_variant_info {
                                * itself and no second kernel is launched */
   int32_t arena_units;        /* units of the arena the run lists of all environments share for their overflow (0 until the first
                                * launch allocates it); a scene that finds it exhausted flags its environment */
-  int32_t team_waves;         /* small batches: waves per environment of the cover kernel's TEAM build (one per band of output
-                               * rows; every wave runs the state phase for itself, wave w covers band w's canvas rows), 0: one wave */
+  int32_t reserved_;
   int64_t run_list_bytes;     /* device memory of the hand-off lists: fixed parts + arena (0 until the first launch) */
 } swb_variant_info;
 int swb_variant(swb_handle h, swb_variant_info* out);

@@ -117,7 +117,7 @@ class SwbVariantInfo(C.Structure):
   _fields_ = [('nw', C.c_int32), ('ncol', C.c_int32), ('vs', C.c_int32), ('lds_bytes_per_wave', C.c_int32),
               ('waves_per_simd', C.c_int32), ('resample_waves_per_simd', C.c_int32), ('n_bands', C.c_int32),
               ('n_column_groups', C.c_int32), ('run_cap', C.c_int32), ('paint_in_cover', C.c_int32),
-              ('arena_units', C.c_int32), ('team_waves', C.c_int32), ('run_list_bytes', C.c_int64)]
+              ('arena_units', C.c_int32), ('reserved_', C.c_int32), ('run_list_bytes', C.c_int64)]
 
 
 FACTOR_UNIFORM_F32, FACTOR_UNIFORM_INT, FACTOR_DISCRETE = 0, 1, 2

@@ -105,11 +105,8 @@ struct swb_engine {
   int32_t* d_env_state = nullptr;    // swb_get_env_state's 20-byte record
   int arena_override = -1;           // SWB_ARENA_UNITS (tests): units of the shared arena; -1: sized from the batch
   int run_cap_worst = 0;             // (max(4, S + 1) canvas heights + 1: what a list reserves until swb_trim_run_lists)
-  int team = 0;                      // waves per environment of the cover kernel's TEAM build (0: not used by this handle)
-  bool no_team = false;              // SWB_NO_TEAM
   bool lists_trimmed = false;        // the lists have been cut down to what the launches so far needed
   bool lists_valid = false;          // the last launch wrote them (it rendered through the second kernel)
-  bool lists_team = false;           // ... as parts per band (the TEAM build)
   int32_t *d_band_y0 = nullptr, *d_band_first = nullptr, *d_band_lo = nullptr, *d_cg_lo = nullptr, *d_cg_hi = nullptr;
   uint32_t* d_v_break = nullptr;
   // live sprite overrides (swb_set_sprite_attr), allocated at the first call
@@ -136,18 +133,14 @@ typedef void (*kernel_fn)(const swb_params);
 
 // cover kernel by canvas width (NW 32-pixel words per canvas row); resample kernel by the output rows a canvas
 // row can feed at once (VS)
-struct variant { int nw; kernel_fn fn, fn_ov, fn_paint, fn_paint_ov, fn_team; size_t lds_fixed, outrow_bytes; };
+struct variant { int nw; kernel_fn fn, fn_ov, fn_paint, fn_paint_ov; size_t lds_fixed, outrow_bytes; };
 
 template <int NW>
 variant make_variant() {
   const size_t outrow = 528;          // wave_lds::outrow is build_all_edges' scratch (132 dwords)
   kernel_fn paint = nullptr, paint_ov = nullptr;       // the builds that paint the frame themselves: canvases of up to 64 px only
   if constexpr (NW == 2) { paint = swb_cover_kernel<NW, false, true>; paint_ov = swb_cover_kernel<NW, true, true>; }
-  // the build for small batches (a workgroup of nbands waves per environment): images of up to 64 columns on canvases of 65 ..
-  // 320 px -- BASELINE configs[1] among them
-  kernel_fn team = nullptr;
-  if constexpr (NW == 4 || NW == 5 || NW == 10) team = swb_cover_kernel<NW, false, false, true>;
-  return {NW, swb_cover_kernel<NW>, swb_cover_kernel<NW, true>, paint, paint_ov, team, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
+  return {NW, swb_cover_kernel<NW>, swb_cover_kernel<NW, true>, paint, paint_ov, (sizeof(wave_lds<NW>) + outrow + 15) & ~(size_t)15, outrow};
 }
 
 const variant kVariants[] = {make_variant<2>(), make_variant<4>(), make_variant<5>(), make_variant<10>(), make_variant<20>()};
@@ -304,10 +297,7 @@ int restore_run_list_reservation(swb_engine* h) {
   if (!h->lists_trimmed) return 0;
   if (int rc = drop_run_lists(h)) return rc;
   h->lists_trimmed = false;
-  if (!getenv("SWB_RUN_CAP")) {
-    h->p.run_cap = h->run_cap_worst;
-    if (h->team) { h->p.sub_cap = h->run_cap_worst; h->p.run_cap = h->team * h->p.sub_cap; }
-  }
+  if (!getenv("SWB_RUN_CAP")) h->p.run_cap = h->run_cap_worst;
   return 0;
 }
 
@@ -360,14 +350,9 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   if (lds > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds);
   // engines on which a sprite setter has been called run the build that reads the per-environment overrides
   const bool paint = h->p.AA == 1 && h->p.ncg == 1 && out && out->obs && !h->no_paint_in_cover && v->fn_paint;
-  kernel_fn fn = paint ? (h->d_ov_flag ? v->fn_paint_ov : v->fn_paint) : (h->d_ov_flag ? v->fn_ov : v->fn);
-  // the TEAM build: a rendering step of a small batch without setter overrides (its lists have a part per band: swb_create)
-  const bool team = h->team && v->fn_team && !h->d_ov_flag && !paint && p.obs && p.nbands > 1 && p.nbands <= h->team;
-  if (team) fn = v->fn_team;
-  const size_t lds_block = team ? lds * (size_t)p.nbands + 64 : lds;      // (TEAM: a part per wave + the waves' error flags)
-  if (lds_block > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block));
-  if (lds_block > 160 * 1024) return fail(SWB_ERR_INVALID, "LDS request %zu B exceeds 160 KiB", lds_block);
+  const kernel_fn fn = paint ? (h->d_ov_flag ? v->fn_paint_ov : v->fn_paint) : (h->d_ov_flag ? v->fn_ov : v->fn);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // first launch, a new pool that shrank the LDS footprint (more waves resident), or the switch to the override build -- not
   // the switch between the painting and the plain build of a family, which alternating launches with and without an
   // observation buffer make at every launch (the cache is keyed on the family's plain build)
@@ -407,12 +392,8 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
     if (p.N > 2 * slots) p.prio_levels &= ~2;          // (cover waves' priorities: measured +1.3 % at three rounds of waves)
   }
   // (cost-ordered: block b serves rank b / 8 of shard b % 8; a shard holds up to cost_cap environments)
-  p.team = team ? p.nbands : 0;
-  if (team) {                            // no cost-ordered dispatch: every wave of either kernel is resident from the start
-    p.cost_cnt = nullptr; p.cost_list = nullptr; p.ccost_list = nullptr; p.cover_order = 0;
-  }
   auto launch_cover = [&](int e0, int e1) {
-    hipLaunchKernelGGL(fn, dim3(e1 - e0), dim3(SWB_WAVE * (team ? p.nbands : 1)), lds_block, stream, p);
+    hipLaunchKernelGGL(fn, dim3(e1 - e0), dim3(SWB_WAVE), lds, stream, p);
   };
   auto launch_resample = [&](int e0, int e1, hipStream_t st) {
     const int blocks_x = p.cost_cnt ? SWB_COST_SHARDS * ((p.cost_cap + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK)
@@ -439,7 +420,6 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   }
   h->cover_lists_filed = p.obs && p.ccost_list;
   h->lists_valid = p.obs && !p.paint_in_cover;
-  h->lists_team = team;
   h->launch_phase = (h->launch_phase + 1) % 3;
   h->launch_parity ^= 1;
   if (h->timing) {
@@ -574,23 +554,7 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   // its frame short of a batch of rows) -- never silently.  A new pool (swb_set_pool / swb_sample_pool) restores the reservation.
   h->run_cap_worst = std::max(4, p.S + 1) * p.Hc + 1;
   p.run_cap = h->run_cap_worst;
-  // Small batches (at most one round of cover waves even with a wave per band): the TEAM build of the cover kernel, a workgroup of
-  // nbands waves per environment, each listing the canvas rows of its band into its own part of the environment's list
-  // (swb_cover_kernel, TEAM) -- every part as large as a whole list would be.
-  h->no_team = getenv("SWB_NO_TEAM") != nullptr;
-  {
-    const variant* v0 = pick_variant(p.Wc);
-    const long long slots = (long long)std::max(h->cus, 1) * 4 * SWB_COVER_WAVES(v0->nw);
-    const bool forced = getenv("SWB_TEAM") != nullptr;                   // tests: whatever the batch
-    if (v0->fn_team && !h->no_team && p.AA != 1 && (p.Wo + 63) / 64 == 1 && h->nbands > 1 &&
-        ((long long)p.N * h->nbands <= slots || forced))
-      h->team = h->nbands;
-  }
-  if (h->team) { p.sub_cap = h->run_cap_worst; p.run_cap = h->team * p.sub_cap; }
-  if (const char* x = getenv("SWB_RUN_CAP")) {                                       // tests
-    p.run_cap = std::max(8, atoi(x));
-    if (h->team) { p.sub_cap = p.run_cap; p.run_cap = h->team * p.sub_cap; }
-  }
+  if (const char* x = getenv("SWB_RUN_CAP")) p.run_cap = std::max(8, atoi(x));      // tests
   if (const char* x = getenv("SWB_ARENA_UNITS")) h->arena_override = std::max(0, atoi(x));   // tests (0: no arena)
   const size_t NS = (size_t)p.N * p.S;
   int rc = 0;
@@ -1026,24 +990,13 @@ int swb_trim_run_lists(swb_handle h, int32_t* run_cap_out, void* stream) {
   std::vector<uint32_t> hdr((size_t)p.N * SWB_RHDR_DWORDS);
   HIP_TRY(hipMemcpy(hdr.data(), h->d_rhdr, hdr.size() * 4, hipMemcpyDeviceToHost));
   uint32_t longest = 0;
-  for (int n = 0; n < p.N; ++n) {
-    const uint32_t* e = hdr.data() + (size_t)n * SWB_RHDR_DWORDS + SWB_RHDR_GROUPS;
-    if (h->lists_team) {               // the parts of the bands: [start, end) in the band slots of column groups 0 and 1
-      for (int b = 0; b < p.nbands; ++b)
-        if (e[SWB_RHDR_GSTRIDE + 1 + b] >= e[1 + b] && e[1 + b] == (uint32_t)(b * p.sub_cap))      // (a part that moved to the arena: not measured)
-          longest = std::max(longest, e[SWB_RHDR_GSTRIDE + 1 + b] - e[1 + b]);
-        else longest = std::max(longest, (uint32_t)p.sub_cap / 2);
-    } else {
-      for (int g = 0; g < p.ncg; ++g) longest = std::max(longest, e[g * SWB_RHDR_GSTRIDE]);
-    }
-  }
-  const int own = h->team ? p.sub_cap : p.run_cap;
-  if (longest >= (uint32_t)own) return SWB_OK;                       // (cannot be: keep what there is)
+  for (int n = 0; n < p.N; ++n)
+    for (int g = 0; g < p.ncg; ++g) longest = std::max(longest, hdr[(size_t)n * SWB_RHDR_DWORDS + SWB_RHDR_GROUPS + g * SWB_RHDR_GSTRIDE]);
+  if (longest >= (uint32_t)p.run_cap) return SWB_OK;                 // (cannot be: keep what there is)
   const int want = std::max(p.Hc / 2, (int)(longest + longest / 4 + 16)) + 1;
-  if (want >= own) return SWB_OK;                                    // nothing to gain
+  if (want >= p.run_cap) return SWB_OK;                              // nothing to gain
   if (int rc = drop_run_lists(h)) return rc;
-  if (h->team) { h->p.sub_cap = want; h->p.run_cap = h->team * want; }
-  else h->p.run_cap = want;
+  h->p.run_cap = want;
   h->lists_trimmed = true;
   if (int rc = ensure_handoff_tables(h)) return rc;
   if (run_cap_out) *run_cap_out = h->p.run_cap;
@@ -1353,7 +1306,7 @@ int swb_variant(swb_handle h, swb_variant_info* out) {
   out->run_cap = h->p.run_cap;
   out->paint_in_cover = (h->p.AA == 1 && (h->p.Wo + 63) / 64 == 1 && !h->no_paint_in_cover) ? 1 : 0;
   out->arena_units = h->d_runs ? h->p.arena_units : 0;
-  out->team_waves = (h->team && v->fn_team && !h->d_ov_flag && (h->p.nbands ? h->p.nbands : h->nbands) > 1) ? (h->p.nbands ? h->p.nbands : h->nbands) : 0;
+  out->reserved_ = 0;
   out->run_list_bytes = h->d_runs ? ((int64_t)h->p.arena_base + h->p.arena_units + 4) * 8 : 0;
   return SWB_OK;
 }

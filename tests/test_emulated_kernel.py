@@ -558,65 +558,3 @@ def test_emulated_kernel_tasks_that_filter_on_position(name, f32):
     prev = want['reward']
   assert flips > 20
   eng.close()
-
-
-@pytest.mark.parametrize('bands', [2, 3, 4, 8])
-def test_emulated_team_build_of_the_cover_kernel(monkeypatch, bands):
-  """Round 6, small batches: the TEAM build of the cover kernel -- a workgroup of `bands` waves per environment, every wave
-  running the state phase for itself (one barrier behind the loads of the live state; wave 0 alone stores), wave w covering the
-  canvas rows of band w into its own part of the environment's run list.  State, rewards, step types and frames are those of
-  the oracle, step after step (auto-resets, trimmed lists, lists that outgrow their part and move to the arena included)."""
-  monkeypatch.delenv('SWB_NO_TEAM', raising=False)
-  monkeypatch.setenv('SWB_TEAM', '1')
-  monkeypatch.setenv('SWB_BANDS', str(bands))
-  for name, n_envs, aa in (('goal_s5', 6, 5), ('cluster_s5', 5, 5), ('sorting_s4', 3, 4), ('tiny_s6', 4, 5), ('wide_s4', 3, 5)):
-    cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=3, seed=3, anti_aliasing=aa)
-    eng = _emu(cfg, pool)
-    eng.step(sample(np.random.default_rng(0)))
-    assert eng.variant()['team_waves'] == eng.variant()['n_bands'] > 1, eng.variant()
-    eng.close()
-    _run(name, n_envs, 7, aa, seed=3)
-  # a part too small for its band: the list moves to the arena (several times), nothing changes
-  monkeypatch.setenv('SWB_RUN_CAP', '8')
-  monkeypatch.setenv('SWB_ARENA_UNITS', str(1 << 20))
-  _run('cluster_s5', 5, 4, 5, seed=4)
-  _run('wide_s4', 3, 3, 5, seed=4)
-
-
-def test_emulated_team_build_is_not_used_where_it_does_not_apply(monkeypatch):
-  """Batches of more than a round of waves, images wider than 64 columns, anti_aliasing = 1, one band: the plain build."""
-  monkeypatch.delenv('SWB_NO_TEAM', raising=False)
-  for env, name, n_envs, aa in ((None, 'cluster_s5', 4, 5), ('1', 'geom_160x48', 2, 3), ('1', 'cluster_s5', 3, 1)):
-    if env:
-      monkeypatch.setenv('SWB_TEAM', env)
-      monkeypatch.setenv('SWB_BANDS', '4')
-    cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=2, seed=0, anti_aliasing=aa)
-    eng = _emu(cfg, pool)
-    eng.step(sample(np.random.default_rng(0)))
-    v = eng.variant()
-    if env is None:      # the emulated device has 256 CUs: 4 environments x 2 bands is a small batch, the team build applies
-      assert v['team_waves'] in (0, v['n_bands'])
-    else:
-      assert v['team_waves'] == 0, (name, v)
-    eng.close()
-
-
-@pytest.mark.parametrize('name', [c for c in _util.golden_cases() if c.startswith(('cobra_', 'position_'))])
-def test_emulated_team_build_reproduces_the_reference_fixtures(monkeypatch, name):
-  """tests/golden/*.npz (the reference's own outputs) through the TEAM build of the cover kernel (64-column images)."""
-  monkeypatch.delenv('SWB_NO_TEAM', raising=False)
-  monkeypatch.setenv('SWB_TEAM', '1')
-  monkeypatch.setenv('SWB_BANDS', '4')
-  cfg, pool, z = _util.load_golden(name)
-  eng = _emu(cfg, pool)
-
-  def step(a):
-    eng.step(a)
-    return eng.outputs_host()
-
-  short = {k: z[k] for k in z.files}
-  short['actions'] = z['actions'][:40]
-  _util.check_against_golden(eng, cfg, short, eng.state, step, 'emulated team build ' + name)
-  v = eng.variant()
-  assert v['team_waves'] == v['n_bands'] > 1 or cfg.anti_aliasing == 1 or cfg.image_h > 64 or v['nw'] < 4, v
-  eng.close()

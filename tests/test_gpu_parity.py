@@ -9,7 +9,6 @@ import numpy as np
 import pytest
 
 from spriteworld_amd import workloads
-from tests import _util
 
 pytestmark = pytest.mark.gpu
 
@@ -332,49 +331,4 @@ def test_tasks_that_filter_on_position(name, f32):
       flips += int((want['reward'] != prev).sum())
     prev = want['reward']
   assert flips > 200
-  eng.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('bands', [2, 4, 8])
-def test_team_build_of_the_cover_kernel(monkeypatch, bands):
-  """Round 6, small batches: a workgroup of `bands` waves per environment -- every wave runs the state phase for itself (one
-  barrier behind the loads of the live state, wave 0 alone stores), wave w covers the canvas rows of band w.  Everything the step
-  returns equals the oracle's, step after step, at the sizes the engine picks the build for by itself (1024 environments: a
-  round of waves) and below; lists that outgrow their part move to the arena."""
-  from spriteworld_amd import engine
-  monkeypatch.delenv('SWB_NO_TEAM', raising=False)
-  monkeypatch.setenv('SWB_BANDS', str(bands))
-  for name, n_envs, aa in (('goal_s5', 1024 if bands == 4 else 96, 5), ('cluster_s5', 200, 5), ('sorting_s4', 64, 4), ('tiny_s6', 48, 5),
-                           ('wide_s4', 33, 5), ('ragged_s16', 40, 5)):
-    cfg, pool, sample = workloads.build(name, n_envs, episodes_per_env=3, seed=3, anti_aliasing=aa)
-    eng = engine.Engine(cfg, pool)
-    eng.step(sample(np.random.default_rng(0)))
-    v = eng.variant()
-    assert v['team_waves'] == v['n_bands'] > 1, (name, v)
-    eng.close()
-    _run(name, n_envs, 7, aa, seed=3)
-  monkeypatch.setenv('SWB_RUN_CAP', '8')
-  monkeypatch.setenv('SWB_ARENA_UNITS', str(1 << 22))
-  _run('cluster_s5', 64, 4, 5, seed=4)
-  _run('wide_s4', 16, 3, 5, seed=4)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('name', [c for c in _util.golden_cases() if c.startswith(('cobra_', 'position_'))])
-def test_team_build_reproduces_the_reference_fixtures(monkeypatch, name):
-  """tests/golden/*.npz (the reference's own outputs) through the TEAM build of the cover kernel."""
-  from spriteworld_amd import engine
-  monkeypatch.delenv('SWB_NO_TEAM', raising=False)
-  monkeypatch.setenv('SWB_BANDS', '4')
-  cfg, pool, z = _util.load_golden(name)
-  eng = engine.Engine(cfg, pool)
-
-  def step(a):
-    eng.step(a)
-    return eng.outputs_host()
-
-  _util.check_against_golden(eng, cfg, z, eng.state, step, 'HIP team build ' + name)
-  v = eng.variant()
-  assert v['team_waves'] == v['n_bands'] > 1 or cfg.anti_aliasing == 1 or cfg.image_h > 64 or v['nw'] < 4, v
   eng.close()
