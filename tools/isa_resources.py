@@ -22,10 +22,9 @@ def kernels_of(asm):
     name = re.search(r'\.name:\s+(\S+)', block).group(1)
     if 'swb_' not in name:
       continue
-    m = re.search(r'swb_cover_kernelILi(\d+)ELb([01])ELb([01])ELb([01])E', name)
+    m = re.search(r'swb_cover_kernelILi(\d+)ELb([01])ELb([01])E', name)
     if m:
-      key = 'swb_cover_kernel<%s%s%s%s>' % (m.group(1), ',OV' if m.group(2) == '1' else '', ',PAINT' if m.group(3) == '1' else '',
-                                          ',TEAM' if m.group(4) == '1' else '')
+      key = 'swb_cover_kernel<%s%s%s>' % (m.group(1), ',OV' if m.group(2) == '1' else '', ',PAINT' if m.group(3) == '1' else '')
     else:
       m = re.search(r'swb_resample_kernelILi(\d+)E', name)
       key = 'swb_resample_kernel<%s>' % m.group(1) if m else re.sub(r'^_Z\d+', '', name).split('1')[0] if False else None
