@@ -10,7 +10,7 @@
 # usage: ROUND=r04 tools/final_evidence.sh [TAG]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r06}
 TAG=${1:-${ROUND}final}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -43,8 +43,16 @@ pmcs() {   # tag workload aa
 }
 pmcs default cluster_s5 5
 
-stamp "default bench line, the driver's command, launch convergence"
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+stamp "default bench line, the driver's command (device clocks sampled beside both), launch convergence"
+# (round-5 review: is the gap between the 20-step and the 200-step line the device's clocks?  rocm-smi sampled every 50 ms)
+clocks() { while true; do echo "$(date +%s.%N) $(rocm-smi --showclocks 2>/dev/null | grep -E 'sclk|mclk' | tr -s ' ' | tr '\n' ';')"; sleep 0.05; done; }
+clocks > $OUT/clocks_default.txt & CPID=$!
+python bench.py --no-cpu-baseline > $OUT/bench_default_nocpu.json 2> $OUT/bench_default.err
+kill $CPID; wait $CPID 2>/dev/null
+clocks > $OUT/clocks_driver_cmd.txt & CPID=$!
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_cmd_nocpu.json 2>> $OUT/bench_default.err
+kill $CPID; wait $CPID 2>/dev/null
+python bench.py > $OUT/bench_default.json 2>> $OUT/bench_default.err
 tail -c 700 $OUT/bench_default.json; echo
 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench_default.err
 python tools/launch_convergence.py cluster_s5 8192 5 64 > $OUT/convergence_headline.json 2> $OUT/convergence.err
