@@ -49,6 +49,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_ACTION_SETS = 16
 
 
+def handoff_bytes_per_env(variant, n_envs):
+  b = variant.get('run_list_bytes')
+  return round(b / max(n_envs, 1), 1) if b else 0
+
+
 def algorithmic_bytes(cfg):
   """A = 3*H*W + 28*S + 17 + action_bytes per env-step."""
   action_bytes = 8 if cfg.action_space == 2 else 16
@@ -125,32 +130,33 @@ class TimedRun(object):
   def inputs(self):
     return self.cfg, self.pool, self.acts_host, self.data
 
-  def go(self, barrier=None, gate=None):
-    """`gate` (N > 1): called after the warm-up, returns False when another rank failed to set up -- then nothing is timed
-    and False is returned (every rank leaves together instead of hanging in the barrier)."""
+  def go(self, barrier=None):
+    """The --warmup steps, then exactly `steps` timed ones between two barriers (N > 1) and two device synchronisations.
+    N > 1: the ranks have been through the gate by now (gpu_run), so every rank runs the same sequence of collectives whatever
+    happens on it: an exception in the warm-up or in the timed region is carried in the result (`error`) instead of being
+    raised past a barrier the other ranks are waiting in."""
     import torch
     eng, acts = self.eng, self.acts
-    for i in range(self.warmup):
-      eng.step(acts[i % N_ACTION_SETS])
-    torch.cuda.synchronize(eng.device)
-    if gate is not None and not gate(None):
-      eng.close()
-      return False
-    # from here on every rank runs the same sequence of collectives whatever happens on it: an exception in the timed
-    # region is carried in the result (`error`) instead of being raised past the barrier the other ranks are waiting in
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     self.event_ms = 0.0
+    try:
+      for i in range(self.warmup):
+        eng.step(acts[i % N_ACTION_SETS])
+      torch.cuda.synchronize(eng.device)
+    except Exception as e:  # pylint: disable=broad-except
+      self.run_error = repr(e)
     if barrier:
       barrier()
     torch.cuda.synchronize(eng.device)
     t0 = time.perf_counter()
     try:
-      ev0.record()                                   # (torch's current stream: the one the engine launches on)
-      for i in range(self.steps):
-        eng.step(acts[i % N_ACTION_SETS])
-      ev1.record()
-      torch.cuda.synchronize(eng.device)
-      self.event_ms = float(ev0.elapsed_time(ev1))
+      if self.run_error is None:
+        ev0.record()                                 # (torch's current stream: the one the engine launches on)
+        for i in range(self.steps):
+          eng.step(acts[i % N_ACTION_SETS])
+        ev1.record()
+        torch.cuda.synchronize(eng.device)
+        self.event_ms = float(ev0.elapsed_time(ev1))
     except Exception as e:  # pylint: disable=broad-except
       self.run_error = repr(e)
     if barrier:
@@ -159,12 +165,14 @@ class TimedRun(object):
     self.elapsed = time.perf_counter() - t0
     return True
 
-  def ramp(self, ms):
-    """Keeps the device busy with this engine's steps for `ms` milliseconds (untimed); returns the steps taken."""
+  def ramp(self, ms, until=None):
+    """Keeps the device busy with this engine's steps for `ms` milliseconds (untimed) and, after that, for as long as
+    `until()` is false (N > 1: until every rank has got this far -- an idle device drops its clocks within milliseconds, and
+    a rank that waited idle in a barrier would start its timed steps on a cold device); returns the steps taken."""
     import torch
     t0, k = time.perf_counter(), 0
-    while (time.perf_counter() - t0) * 1e3 < ms:
-      for _ in range(16):
+    while (time.perf_counter() - t0) * 1e3 < ms or (until is not None and not until() and time.perf_counter() - t0 < 60.0):
+      for _ in range(8):
         self.eng.step(self.acts[k % N_ACTION_SETS])
         k += 1
       torch.cuda.synchronize(self.eng.device)
@@ -220,14 +228,22 @@ class TimedRun(object):
                 data=getattr(self, 'data', 'synthetic'))
 
 
-def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None, verify=0, before=None, protocol_8d=None):
-  """One timed run, start to end.  `before(run)`: called once the engine and its action sets are on the device, before the
-  first warm-up step (the clock ramp: see main()).  Returns None when the gate closed."""
+def gpu_run(name, n_envs, steps, warmup, aa, device, barrier=None, seed=0, gate=None, verify=0, before=None, after_gate=None,
+            protocol_8d=None):
+  """One timed run, start to end.  `before(run)`: called once the engine and its action sets are on the device (builds the
+  clock-ramp twin: see main()); `gate` (N > 1): every rank reports whether it could set up -- returns False when some rank could
+  not, then nothing is timed and None is returned (every rank leaves together instead of hanging in a barrier); it also brings
+  the ranks to the same point in time, so `after_gate()` (the clock ramp; must not raise) and the warm-up steps behind it end
+  on every rank within microseconds of each other and no device idles in the barrier in front of the timed steps."""
   run = TimedRun(name, n_envs, steps, warmup, aa, device, seed=seed, verify=verify, protocol_8d=protocol_8d).build()
   if before is not None:
     before(run)
-  if not run.go(barrier=barrier, gate=gate):
+  if gate is not None and not gate(None):
+    run.close()
     return None
+  if after_gate is not None:
+    after_gate()
+  run.go(barrier=barrier)
   return run.finish()
 
 
@@ -471,6 +487,8 @@ def assemble_line(args, res, elapsed):
            'frac_frames_only': (obs_bytes * args.envs_per_gpu / resample_s / 1e9 / HBM_PEAK_GBS) if resample_s > 0 else None},
       ],
       'lds_bytes_per_wave': variant['lds_bytes_per_wave'], 'waves_per_simd': variant['waves_per_simd'],
+      # device memory of the hand-off lists between the two kernels (fixed parts + arena, after the engine's trim) per environment
+      'handoff_list_bytes_per_env': handoff_bytes_per_env(variant, args.envs_per_gpu),
       'build_id': variant['build_id'],
   }
   if second.startswith('none'):
@@ -603,18 +621,39 @@ def main():
   # run AFTER the headline, every engine built first, the first of them behind a ramp of its own.
   ramp_info = {}
 
-  def clock_ramp(run):
+  def clock_ramp_build(run):
     ramp_info['data'] = run.data
     if args.ramp_ms <= 0:
       return
-    twin = TimedRun(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device, seed=rank + 1000).build(run.inputs())
+    # (closed BEHIND the timed region: freeing its buffers in front of it idles the device for milliseconds, and an idle device
+    # drops its clocks again -- tools/exp_warm_engine.py: a fresh engine's launches 5 .. 24 take +4.4 % out of idle, +1.6 %
+    # directly behind another engine's steps; the driver's 5 + 20 steps +0.8 % with the twin kept, gpurun_out/r06l/ab.txt)
+    ramp_info['twin'] = TimedRun(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device, seed=rank + 1000).build(run.inputs())
+
+  def clock_ramp_go():
+    """Behind the gate (N > 1: every rank at the same point in time).  Never raises: a failing twin only costs the ramp."""
+    twin, steps_taken = ramp_info.get('twin'), 0
     try:
-      twin.go()
-      ramp_info['cold_ms_per_step'] = twin.event_ms / max(args.steps, 1)
-      ramp_info['cold_wall_ms_per_step'] = twin.elapsed / max(args.steps, 1) * 1e3
-      ramp_info['clock_ramp_steps'] = twin.ramp(args.ramp_ms)
-    finally:
-      twin.close()
+      if twin is not None:
+        twin.go()
+        if twin.run_error is not None:
+          raise RuntimeError(twin.run_error)
+        ramp_info['cold_ms_per_step'] = twin.event_ms / max(args.steps, 1)
+        ramp_info['cold_wall_ms_per_step'] = twin.elapsed / max(args.steps, 1) * 1e3
+        steps_taken = twin.ramp(args.ramp_ms)
+    except Exception as e:  # pylint: disable=broad-except
+      ramp_info['ramp_error'], twin = repr(e), None
+    if dist is not None and args.ramp_ms > 0:
+      # N > 1: the ramp lasts until EVERY rank has done its --ramp-ms -- one all-reduce (issued by every rank, whatever happened
+      # to its twin) polled while the twin keeps stepping, so that no device waits idle for a slower rank
+      work = dist.all_reduce(torch.zeros(1, device='cpu' if dist.get_backend() == 'gloo' else 'cuda'), async_op=True)
+      try:
+        if twin is not None:
+          steps_taken += twin.ramp(0.0, until=work.is_completed)
+      except Exception as e:  # pylint: disable=broad-except
+        ramp_info['ramp_error'] = repr(e)
+      work.wait()
+    ramp_info['clock_ramp_steps'] = steps_taken
 
   extra = {}
   extra_runs = []
@@ -677,7 +716,7 @@ def main():
       extra[label] = {'env_steps_per_s': n * short / r['elapsed'], 'kernel': r['variant']['kernel'], 'kernel_ms': ks * 1e3,
                       'cover_ms': r['cover_ms'] / max(r['launches'], 1), 'resample_ms': r['resample_ms'] / max(r['launches'], 1),
                       'hbm_GBs': r['a_bytes'] * n / ks / 1e9, 'hbm_frac': r['a_bytes'] * n / ks / 1e9 / HBM_PEAK_GBS,
-                      'env_errors': r['errors']}
+                      'env_errors': r['errors'], 'handoff_list_bytes_per_env': handoff_bytes_per_env(r['variant'], n)}
 
   res = None
   gated = [False]                            # this rank has been through the gate (set by the wrapper below)
@@ -690,7 +729,7 @@ def main():
     res = gpu_run(args.workload, args.envs_per_gpu, args.steps, args.warmup, args.aa, device,
                   barrier=barrier, seed=rank, gate=gate_once if dist is not None else None,
                   verify=64 if (rank == 0 and not args.no_verify) else 0,
-                  before=clock_ramp,
+                  before=clock_ramp_build, after_gate=clock_ramp_go,
                   protocol_8d=((rank * args.envs_per_gpu, args.gpus * args.envs_per_gpu)
                                if (args.protocol == '8d' and args.workload in ('cluster_s5', 'goal_s5')) else None))
   except Exception as e:  # pylint: disable=broad-except
@@ -700,6 +739,8 @@ def main():
       gate_once('rank %d: %r' % (rank, e))
     # (after the gate gpu_run raises nothing: failures of the timed region come back in res['error'], so that every
     # rank runs the same collectives below)
+  if ramp_info.get('twin') is not None:
+    ramp_info.pop('twin').close()
   if dist is None and res is not None and res.get('error'):
     raise SystemExit('timed region failed: ' + res['error'])
   per_rank = None

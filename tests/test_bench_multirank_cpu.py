@@ -83,6 +83,17 @@ def test_a_rank_that_fails_in_the_timed_region_gives_one_line_with_rank_errors_a
   assert [e['rank'] for e in d['rank_errors']] == [1] and 'injected' in d['rank_errors'][0]['error']
 
 
+def test_a_rank_that_fails_in_its_warm_up_steps_behind_the_gate_gives_one_line_with_rank_errors_and_no_hang():
+  # (the gate comes BEFORE the clock ramp and the warm-up steps since round 6 -- it aligns the ranks in time --, so a failure in
+  # the warm-up is carried past the barriers like one in the timed region)
+  proc, lines = _launch(['--ramp-ms', '0'], fault='timed:1', fault_at=1, timeout=300)
+  assert proc.returncode == 0, proc.stderr[-2000:]
+  assert len(lines) == 1, proc.stdout[-2000:]
+  d = json.loads(lines[0])
+  assert d['value'] is None
+  assert [e['rank'] for e in d['rank_errors']] == [1] and 'injected' in d['rank_errors'][0]['error']
+
+
 def test_gather_obs_runs_both_schedules_on_two_ranks():
   proc, lines = _launch(['--ramp-ms', '0', '--gather-obs', '--no-verify'])
   assert proc.returncode == 0, proc.stderr[-2000:]
