@@ -398,7 +398,8 @@ int launch(swb_engine* h, const void* actions, const swb_outputs* out, int rende
   auto launch_resample = [&](int e0, int e1, hipStream_t st) {
     const int blocks_x = p.cost_cnt ? SWB_COST_SHARDS * ((p.cost_cap + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK)
                                     : (e1 - e0 + SWB_RS_WAVES_PER_BLOCK - 1) / SWB_RS_WAVES_PER_BLOCK;
-    const dim3 grid(blocks_x, p.nbands, p.cost_cnt ? 1 : p.ncg);      // (cost-ordered: a list entry names its column group)
+    // (cost-ordered: a list entry names its column group -- and, for small batches, its band: swb_params::band_tasks)
+    const dim3 grid(blocks_x, (p.cost_cnt && p.band_tasks) ? 1 : p.nbands, p.cost_cnt ? 1 : p.ncg);
     hipLaunchKernelGGL(fn2, grid, dim3(SWB_WAVE * SWB_RS_WAVES_PER_BLOCK), lds2, st, p);
   };
   launch_cover(0, c.n_envs);
@@ -491,14 +492,16 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   if (p.Wo > 64 * SWB_MAX_CG) { delete h; return fail(SWB_ERR_INVALID, "image width %d not supported (max %d)", p.Wo, 64 * SWB_MAX_CG); }
   // Bands of output rows per (environment, column group) in the second kernel: a band repeats the 25 canvas rows it
   // shares with the band above, so there are only as many as it takes to give every SIMD its eight waves (small
-  // batches), in bands of at least 16 rows.
+  // batches), in bands of at least 16 rows -- of 8 rows where even those leave the SIMDs at most half full (measured, 64-px
+  // images: 512 environments 0.0311 ms in 8 bands against 0.0354 in 4; 1024 environments 0.0392 against 0.0374 --
+  // gpurun_out/r06n/bands.txt, profiles/r06_experiments/bands_small_batches.txt).
   {
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     const long long resident = (long long)std::max(cus, 1) * 4 * SWB_RS_WAVES_PER_SIMD;
     const long long tasks = (long long)p.N * ((p.Wo + 63) / 64);
     int nb = 1;
-    while (nb < SWB_MAX_BANDS && tasks * nb < resident && p.Ho / (2 * nb) >= 16) nb *= 2;
+    while (nb < SWB_MAX_BANDS && tasks * nb < resident && (p.Ho / (2 * nb) >= 16 || (p.Ho / (2 * nb) >= 8 && tasks * nb * 4 <= resident))) nb *= 2;
     if (const char* x = getenv("SWB_BANDS")) nb = std::max(1, std::min(atoi(x), (int)SWB_MAX_BANDS));
     h->nbands = std::min(nb, p.Ho);
   }
@@ -507,7 +510,18 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   // fitted by every launch (cost_housekeeping), to begin with it is [0, 8 * canvas height)
   p.cost_range0 = std::max(8 * p.Hc, SWB_KEY_BUCKETS_FITTED);      // (a run and its units cost 5 .. 9; a launch later the range is a measured one)
   if (!getenv("SWB_NO_COST_ORDER") && p.N < (1 << 24)) {
-    p.cost_cap = ((p.Wo + 63) / 64) * ((p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS);
+    // Small batches in several bands: a task of the second kernel is one BAND of a list, filed under the band's own cost, once
+    // the launch has four waves or more per SIMD to deal (measured, resample / fill kernel: 2048 environments in 4 bands -9.5 %,
+    // 1024 -2 %, a 128x128 image at anti_aliasing = 1 -22 %; two waves per SIMD, 256 environments in 8 bands, +3 %:
+    // profiles/r06_experiments/band_tasks_ab.txt).
+    {
+      int cus3 = 0;
+      (void)hipDeviceGetAttribute(&cus3, hipDeviceAttributeMultiprocessorCount, device);
+      const long long waves3 = (long long)p.N * ((p.Wo + 63) / 64) * h->nbands;
+      p.band_tasks = (h->nbands > 1 && waves3 >= 4ll * std::max(cus3, 1) * 4 && !getenv("SWB_NO_BAND_TASKS")) ? 1 : 0;
+      if (const char* x = getenv("SWB_BAND_TASKS")) p.band_tasks = (h->nbands > 1 && atoi(x) != 0) ? 1 : 0;      // tests
+    }
+    p.cost_cap = ((p.Wo + 63) / 64) * ((p.N + SWB_COST_SHARDS - 1) / SWB_COST_SHARDS) * (p.band_tasks ? h->nbands : 1);
     std::vector<uint32_t> cnt0(5 * SWB_COST_SET + SWB_COST_WORDS, 0u);
     for (int ph = 0; ph < 3; ++ph) cnt0[SWB_COST_WORD_COVER_SHIFT(ph)] = 12;   // bucket width of the cover kernel's cycle counts: 2^12 to begin with
     for (int par = 0; par < 2; ++par) {                                       // buckets of the second kernel's tasks: [0, cost_range0) to begin with

@@ -109,13 +109,16 @@ def test_emulated_kernel_span_overflow_slots(monkeypatch, name, n_envs, aa):
 
 
 # ---- the hand-off between the two kernels of a step (round 3): bands of output rows, cost-ordered dispatch, list capacity
-@pytest.mark.parametrize('bands', [1, 2, 3, 8])
+@pytest.mark.parametrize('bands,band_tasks', [(1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (8, 0), (8, 1)])
 @pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 3, 5), ('embodied_s12', 2, 5), ('geom_100x60', 2, 3), ('geom_64x256', 2, 1),
                                             ('geom_96x48', 2, 3), ('cluster_s5', 3, 1)])
-def test_emulated_kernel_any_number_of_bands(monkeypatch, bands, name, n_envs, aa):
+def test_emulated_kernel_any_number_of_bands(monkeypatch, bands, name, n_envs, aa, band_tasks):
   """The resample / fill kernel splits an image into bands of output rows (one wave each); a band starts with the output rows
-  already in flight at its first canvas row.  Every band count gives the same frames."""
+  already in flight at its first canvas row.  Every band count gives the same frames -- whether the second kernel's tasks are
+  whole lists (every band of a list in the list's place of the cost order) or single bands filed under their own cost
+  (round 6, swb_params::band_tasks: what launches of four waves or more per SIMD use)."""
   monkeypatch.setenv('SWB_BANDS', str(bands))
+  monkeypatch.setenv('SWB_BAND_TASKS', str(band_tasks))
   _run(name, n_envs, 3, aa)
 
 
@@ -207,6 +210,7 @@ def test_emulated_kernel_run_list_overflow_is_flagged(monkeypatch, run_cap, band
   monkeypatch.setenv('SWB_RUN_CAP', str(run_cap))
   monkeypatch.setenv('SWB_ARENA_UNITS', '0')               # (no shared arena to continue in: the round-5 layout)
   monkeypatch.setenv('SWB_BANDS', str(bands))
+  monkeypatch.setenv('SWB_BAND_TASKS', str(n_envs & 1))    # (either form of the second kernel's tasks)
   for aa, name in ((5, 'cluster_s5'), (1, 'wide_s4')):
     if aa == 1:
       monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')
@@ -237,6 +241,7 @@ def test_emulated_kernel_run_lists_continue_in_the_shared_arena(monkeypatch, run
   monkeypatch.setenv('SWB_RUN_CAP', str(run_cap))
   monkeypatch.setenv('SWB_ARENA_UNITS', str(arena))
   monkeypatch.setenv('SWB_BANDS', str(bands))
+  monkeypatch.setenv('SWB_BAND_TASKS', '1')                # (a moving list shifts the band starts it has recorded -- and their copy in LDS)
   for aa, name, n_envs in ((5, 'cluster_s5', 5), (1, 'geom_160x48', 3), (5, 'embodied_s12', 2)):
     if aa == 1:
       monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')

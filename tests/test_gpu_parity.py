@@ -160,12 +160,20 @@ def test_randomised_configurations(seed):
 
 
 # ---- the hand-off between the two kernels of a step (round 3)
-@pytest.mark.parametrize('bands', [1, 2, 4, 8])
+@pytest.mark.parametrize('bands,band_tasks', [(1, 0), (2, 0), (2, 1), (4, 0), (4, 1), (8, 0), (8, 1)])
 @pytest.mark.parametrize('name,n_envs,aa', [('cluster_s5', 64, 5), ('embodied_s12', 32, 5), ('geom_100x60', 32, 3), ('geom_64x256', 32, 1),
                                             ('cluster_s5', 64, 1)])
-def test_any_number_of_bands(monkeypatch, bands, name, n_envs, aa):
-  """Bands of output rows (one wave of the resample / fill kernel each; small batches use several): same frames."""
+def test_any_number_of_bands(monkeypatch, bands, name, n_envs, aa, band_tasks):
+  """Bands of output rows (one wave of the resample / fill kernel each; small batches use several): same frames, whether a task
+  of the second kernel is a whole list or one band of it filed under its own cost (swb_params::band_tasks)."""
   monkeypatch.setenv('SWB_BANDS', str(bands))
+  monkeypatch.setenv('SWB_BAND_TASKS', str(band_tasks))
+  _run(name, n_envs, 3, aa)
+
+
+@pytest.mark.parametrize('name,n_envs,aa', [('goal_s5', 1024, 5), ('cluster_s5', 2048, 5), ('geom_128x128', 1024, 1), ('embodied_s12', 700, 5)])
+def test_small_batches_file_their_bands_as_tasks_of_their_own(name, n_envs, aa):
+  """BASELINE configs[1]'s size and its neighbours: the engine picks 4 bands and files every band as a task (no switches set)."""
   _run(name, n_envs, 3, aa)
 
 
@@ -249,6 +257,7 @@ def test_run_lists_that_outgrow_their_part_move_to_the_arena(monkeypatch, run_ca
   monkeypatch.setenv('SWB_RUN_CAP', str(run_cap))
   monkeypatch.setenv('SWB_ARENA_UNITS', str(1 << 22))
   monkeypatch.setenv('SWB_BANDS', str(bands))
+  monkeypatch.setenv('SWB_BAND_TASKS', '1')         # (a moving list shifts the band starts it has recorded -- and their copy in LDS)
   _run('cluster_s5', 96, 4, 5)
   _run('embodied_s12', 24, 3, 5)
   monkeypatch.setenv('SWB_NO_PAINT_IN_COVER', '1')

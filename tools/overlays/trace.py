@@ -21,8 +21,8 @@ def apply(files, arg, replace_once):
   # cover kernel: phase stamps through the phase hook (cycles since wave start at the end of phase k -> t[4 + slot])
   replace_once(files, k, '#ifndef SWB_HOOK_PHASE_END\n#define SWB_HOOK_PHASE_END(k)\n#endif\n',
                '#define SWB_HOOK_PHASE_END(k) { if (p.exp_trace && l == 0) p.exp_trace[(size_t)env * 12 + 4 + ((k) == 3 ? 0 : (k) == 4 ? 1 : (k) == 5 ? 2 : 3)] = __builtin_amdgcn_s_memtime() - exp_c0; }\n')
-  replace_once(files, k, '    row_spans rs;\n    coverage_batch2<NW>(p, L, edges, spans, ovf, n, yb, sp_ymin, sp_ymax, sp_a, sp_e0, rs, err);\n    SWB_RESCAN_WITH_OVERFLOW_SLOT()\n    emit_runs(p, spans, ovf, rs, yb, env, runs_env, hdr, base_l, band_l, cost_l, err);\n',
-               '    row_spans rs;\n    const unsigned long long exp_a = __builtin_amdgcn_s_memtime();\n    coverage_batch2<NW>(p, L, edges, spans, ovf, n, yb, sp_ymin, sp_ymax, sp_a, sp_e0, rs, err);\n    SWB_RESCAN_WITH_OVERFLOW_SLOT()\n    const unsigned long long exp_b = __builtin_amdgcn_s_memtime();\n    emit_runs(p, spans, ovf, rs, yb, env, runs_env, hdr, base_l, band_l, cost_l, err);\n    exp_cov += exp_b - exp_a; exp_emit += __builtin_amdgcn_s_memtime() - exp_b; exp_nb += 1;\n')
+  replace_once(files, k, '    row_spans rs;\n    coverage_batch2<NW>(p, L, edges, spans, ovf, n, yb, sp_ymin, sp_ymax, sp_a, sp_e0, rs, err);\n    SWB_RESCAN_WITH_OVERFLOW_SLOT()\n    emit_runs(p, spans, ovf, rs, yb, env, runs_env, hdr, bst, base_l, band_l, cost_l, err);\n',
+               '    row_spans rs;\n    const unsigned long long exp_a = __builtin_amdgcn_s_memtime();\n    coverage_batch2<NW>(p, L, edges, spans, ovf, n, yb, sp_ymin, sp_ymax, sp_a, sp_e0, rs, err);\n    SWB_RESCAN_WITH_OVERFLOW_SLOT()\n    const unsigned long long exp_b = __builtin_amdgcn_s_memtime();\n    emit_runs(p, spans, ovf, rs, yb, env, runs_env, hdr, bst, base_l, band_l, cost_l, err);\n    exp_cov += exp_b - exp_a; exp_emit += __builtin_amdgcn_s_memtime() - exp_b; exp_nb += 1;\n')
   replace_once(files, k, '  int env = blockIdx.x;\n  // ... and, as in the resample kernel, the wave\'s priority follows',
                begin + '  unsigned long long exp_cov = 0, exp_emit = 0, exp_nb = 0;\n  int env = blockIdx.x;\n  // ... and, as in the resample kernel, the wave\'s priority follows')
   replace_once(files, k, '  if (l == 0) ovf_slot_release(p, ovf);\n  if (p.error) {\n    uint32_t e = err & ~SWB_INT_NEED_SLOT;',
