@@ -492,16 +492,16 @@ int swb_create(const swb_config* cfg, int device, swb_handle* out) {
   if (p.Wo > 64 * SWB_MAX_CG) { delete h; return fail(SWB_ERR_INVALID, "image width %d not supported (max %d)", p.Wo, 64 * SWB_MAX_CG); }
   // Bands of output rows per (environment, column group) in the second kernel: a band repeats the 25 canvas rows it
   // shares with the band above, so there are only as many as it takes to give every SIMD its eight waves (small
-  // batches), in bands of at least 16 rows -- of 8 rows where even those leave the SIMDs at most half full (measured, 64-px
-  // images: 512 environments 0.0311 ms in 8 bands against 0.0354 in 4; 1024 environments 0.0392 against 0.0374 --
-  // gpurun_out/r06n/bands.txt, profiles/r06_experiments/bands_small_batches.txt).
+  // batches), in bands of at least 16 rows -- of 8 rows where those fill the SIMDs no more than once (measured, 64-px images:
+  // 512 environments 0.0311 ms in 8 bands against 0.0354 in 4; 1024 environments, every band a task of its own (band_tasks
+  // below), 0.0342 against 0.0366; 2048 environments 0.0498 against 0.0422: profiles/r06_experiments/bands_small_batches.txt).
   {
     int cus = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     const long long resident = (long long)std::max(cus, 1) * 4 * SWB_RS_WAVES_PER_SIMD;
     const long long tasks = (long long)p.N * ((p.Wo + 63) / 64);
     int nb = 1;
-    while (nb < SWB_MAX_BANDS && tasks * nb < resident && (p.Ho / (2 * nb) >= 16 || (p.Ho / (2 * nb) >= 8 && tasks * nb * 4 <= resident))) nb *= 2;
+    while (nb < SWB_MAX_BANDS && tasks * nb < resident && (p.Ho / (2 * nb) >= 16 || (p.Ho / (2 * nb) >= 8 && tasks * nb * 2 <= resident))) nb *= 2;
     if (const char* x = getenv("SWB_BANDS")) nb = std::max(1, std::min(atoi(x), (int)SWB_MAX_BANDS));
     h->nbands = std::min(nb, p.Ho);
   }
