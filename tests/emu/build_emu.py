@@ -81,8 +81,7 @@ def _instrument(text):
   # resample kernel: runs, the canvas rows they stand for, their spans; finished output rows and the untouched ones
   after('      while ((int)(rec.x & 0xffffu) <= next_end) {',
         hook('p3_row_runs') + hook('p3_rows_in_runs', '(long)((rec.x >> 16) & 63u) + 1') + hook('p3_spans', '(long)std::max(1u, rec.x >> 24)'))
-  after('      // finish output row r_first: clip, pack, store; rows above the band only free their slot\n', '     ' + hook('p3_completed_rows') + '\n')
-  after('      if (black && mark[k] == uo) {', hook('p3_clean_rows'))
+  after('        const bool untouched = black && mark[k] == uo;\n', '       ' + hook('p3_completed_rows') + ' if (untouched)' + hook('p3_clean_rows') + '\n')
   # cover kernel: coverage passes and what they emit
   after('    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)sp_a, s);', hook('p2_sprite_passes'))
   after('  rs.cnt = 0; rs.s0 = rs.s1 = rs.s2 = 0u;', hook('p2_batches'))
