@@ -65,7 +65,8 @@ def _rewrite(text, name):
 # SWB_EMU_STATS=1: event counters at a few anchor points of the kernel source (counted by lane 0 of each wave), read back
 # through emu_stats() -- exact dynamic figures for the cost model in DESIGN.md (tools/emu_stats.py).
 _COUNTERS = ('p3_row_runs', 'p3_rows_in_runs', 'p3_spans', 'p3_completed_rows', 'p3_clean_rows', 'p2_batches',
-             'p2_sprite_passes', 'p2_edge_iterations', 'p2_transition_steps', 'run_units', 'p2_chunks', 'p2_packed_passes', 'p2_words')
+             'p2_sprite_passes', 'p2_edge_iterations', 'p2_transition_steps', 'run_units', 'p2_chunks', 'p2_packed_passes', 'p2_words',
+             'p1b_general_iterations', 'p1b_sweeps')
 
 
 def _instrument(text):
@@ -92,6 +93,8 @@ def _instrument(text):
   after('    for (int wc = w0; wc <= w1; wc += NWA) {', hook('p2_chunks'))
   after('        if (!((wbits >> w) & 1u)) continue;         // uniform: not in this chunk\n', '       ' + hook('p2_words') + '\n')
   after('        pk_hlines = __ballot(have && horiz && ed.y0 >= yb && ed.y0 <= yb + 63 && ed.y0 < p.Hc) != 0ull;', hook('p2_packed_passes'))
+  after('      while (__ballot(cand != 0ull)) {', hook('p1b_general_iterations'))
+  after('    const bool base_live = have && (cy0 != cy1) && (cdx != 0.0f);', hook('p1b_sweeps'))
   anchor = '        auto take = [&]() __attribute__((always_inline)) {'
   assert text.count(anchor) == 1, anchor
   text = text.replace(anchor, anchor + hook('p2_transition_steps') + ' ')
