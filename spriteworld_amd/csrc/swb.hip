@@ -630,10 +630,15 @@ int swb_upload_shapes(swb_handle h, const double* verts, const int32_t* offsets,
         best = std::min(best, std::hypot(verts[2 * a] - verts[2 * b], verts[2 * a + 1] - verts[2 * b + 1]));
     dmin[i] = best;
   }
-  if (upload(&h->d_shape_dmin, dmin.data(), (size_t)n_shapes)) return SWB_ERR_HIP;
+  // (both small tables are padded to SWB_MAX_SHAPES entries: a cover wave loads them whole, lane i = entry i, beside its first
+  // round of loads and looks a sprite's shape up with a cross-lane read -- not with a third dependent round trip to memory)
+  dmin.resize(SWB_MAX_SHAPES, 0.0);
+  std::vector<int32_t> off_padded(offsets, offsets + n_shapes + 1);
+  off_padded.resize(SWB_MAX_SHAPES + 1, offsets[n_shapes]);
+  if (upload(&h->d_shape_dmin, dmin.data(), dmin.size())) return SWB_ERR_HIP;
   h->p.shape_dmin = h->d_shape_dmin;
   if (upload(&h->d_shape_verts, verts, (size_t)offsets[n_shapes] * 2)) return SWB_ERR_HIP;
-  if (upload(&h->d_shape_off, offsets, (size_t)n_shapes + 1)) return SWB_ERR_HIP;
+  if (upload(&h->d_shape_off, off_padded.data(), off_padded.size())) return SWB_ERR_HIP;
   h->p.shape_verts = h->d_shape_verts;
   h->p.shape_off = h->d_shape_off;
   h->p.max_verts = maxv;
