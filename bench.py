@@ -647,9 +647,14 @@ def main():
       # N > 1: the ramp lasts until EVERY rank has done its --ramp-ms -- one all-reduce (issued by every rank, whatever happened
       # to its twin) polled while the twin keeps stepping, so that no device waits idle for a slower rank
       work = dist.all_reduce(torch.zeros(1, device='cpu' if dist.get_backend() == 'gloo' else 'cuda'), async_op=True)
+      def arrived():
+        try:
+          return bool(work.is_completed())
+        except Exception:  # pylint: disable=broad-except     (a backend without a completion query: stop polling, wait below)
+          return True
       try:
         if twin is not None:
-          steps_taken += twin.ramp(0.0, until=work.is_completed)
+          steps_taken += twin.ramp(0.0, until=arrived)
       except Exception as e:  # pylint: disable=broad-except
         ramp_info['ramp_error'] = repr(e)
       work.wait()

@@ -141,7 +141,9 @@ def test_bench_line_carries_the_committed_counters_of_this_build():
     if workload == 'cluster_s5' and aa == 5:        # (the made-up kernel time above is about the headline's)
       assert ins['valu_issue_frac_of_step'] < 1.0
     if ins['resample_valu_model_min_per_env']:
-      assert 1.0 <= ins['resample_valu_measured_over_model'] < 2.0
+      # (the model counts 10 per further span and 17 per finished row; the round-6 kernel issues 9 and 16, so a scene of many
+      # spans per run -- 12 sprites at 128x128 -- measures a few per cent BELOW the model)
+      assert 0.9 <= ins['resample_valu_measured_over_model'] < 2.0
     res['variant'] = dict(res['variant'], build_id='0000000000000000')
     stale = bench.assemble_line(args, res, 0.0046)['roofline']
     assert stale['traffic'] is None and stale['instructions'] is None and stale['counters'] == 'stale'

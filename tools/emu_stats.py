@@ -50,7 +50,8 @@ def resample_valu_model(vals):
   issued (swb_kernels.hip.inc, resample loop): per run 2 med3 + 2 address + 1 readlane + 1 sub + 3 mad for the first
   span, 3 shifts + 3 med3 (clip), 18 mads (six output rows in flight x three channels) = 33; 10 per further span; a
   finished row that received something 3 reads + 3 restarts + 6 clip + 2 pack + 1 DPP + 1 perm + 1 offset = 17, an
-  untouched one 1; ~150 per wave of set-up."""
+  untouched one 1; ~150 per wave of set-up.  (Round 6: the kernel issues 9 per further span and 16 per finished row -- the model
+  is kept as it was, so that the figures of the rounds compare; a scene of many spans per run measures slightly below it.)"""
   runs, spans = vals['p3_row_runs'], vals['p3_spans']
   done, clean = vals['p3_completed_rows'], vals['p3_clean_rows']
   return 33 * runs + 10 * (spans - runs) + 17 * (done - clean) + 1 * clean + 150
