@@ -675,6 +675,7 @@ def main():
         # BASELINE configs[3]'s per-GPU share is 8192; this is the same scene with 8x the batch in ONE launch
         # (the launch's fixed fill/drain cost amortised)
         'cluster_s5_65536_aa5': ('cluster_s5', 65536, 5),
+        'cluster_s5_65536_aa1': ('cluster_s5', 65536, 1),
     }.items():
       extra_runs.append((label, TimedRun(nm, n, short, 5, aa, device).build()))
     # the headline batch as two groups of 4096 on two HIP streams: consecutive steps of different groups overlap,
