@@ -37,7 +37,10 @@ def main():
                              ('configs[1], anti_aliasing 1', 'goal_s5_1024_aa1', 1024, None),
                              ('configs[4]: embodied_s12, 12 sprites, 128×128, anti_aliasing 5', 'embodied_s12_128_aa5', 8192, e),
                              ('configs[4], anti_aliasing 1', 'embodied_s12_128_aa1', 8192, None),
-                             ('cluster_s5, 65 536 environments in one launch', 'cluster_s5_65536_aa5', 65536, None)):
+                             ('cluster_s5, 65 536 environments in one launch', 'cluster_s5_65536_aa5', 65536, None),
+                             ('the same, anti_aliasing 1', 'cluster_s5_65536_aa1', 65536, None)):
+    if key not in ex:
+      continue
     x = ex[key]
     t.append(row(label, x['kernel_ms'], n / x['kernel_ms'] * 1e3, x['hbm_frac'], ratio(rec) if rec else '', busy(rec) if rec else ''))
   t.append('| the headline batch as two groups of 4096 on two HIP streams (`EnvironmentGroups`; host wall time) | | %.1f M | | | | |' % (
