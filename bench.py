@@ -810,6 +810,8 @@ def main():
       'how': ('a twin engine of the same workload timed W + K steps cold, then kept the device busy for clock_ramp_ms, before the '
               "timed engine's own W warm-up steps; identical on every rank at every N") if 'cold_ms_per_step' in ramp_info else 'none (--ramp-ms 0)',
   }
+  if 'ramp_error' in ramp_info:
+    out['warmup_effective']['ramp_error'] = ramp_info['ramp_error']
   if 'cold_ms_per_step' in ramp_info:
     cold_s = ramp_info['cold_ms_per_step'] / 1e3
     out['cold'] = {'value': args.envs_per_gpu * args.gpus / cold_s if cold_s > 0 else None, 'unit': 'env-steps/s',
